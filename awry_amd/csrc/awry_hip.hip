@@ -1,0 +1,757 @@
+// awry_hip.hip -- C ABI (include/awry_hip.h) over the gfx950 kernels: device replicas, batch drivers,
+// seed-table construction.  There is deliberately no CPU implementation of count / locate here.
+#include "../../include/awry_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <mutex>
+#include <new>
+#include <stdexcept>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "alphabet.h"
+#include "host_index.h"
+#include "kernels.hip.h"
+#include "sais.hpp"
+
+using namespace awry;
+
+namespace {
+
+thread_local std::string g_last_error;
+
+struct HipError : std::runtime_error { using std::runtime_error::runtime_error; };
+struct ArgError : std::runtime_error { using std::runtime_error::runtime_error; };
+struct QueryError : std::runtime_error { using std::runtime_error::runtime_error; };
+struct NoDeviceError : std::runtime_error { using std::runtime_error::runtime_error; };
+
+#define HIP_CHECK(expr)                                                                              \
+  do {                                                                                               \
+    hipError_t _e = (expr);                                                                          \
+    if (_e != hipSuccess)                                                                            \
+      throw HipError(std::string(#expr) + " failed: " + hipGetErrorString(_e) + " (" + __FILE__ + ":" + \
+                     std::to_string(__LINE__) + ")");                                                \
+  } while (0)
+
+template <class F>
+int guarded(F&& fn) {
+  try {
+    fn();
+    return AWRY_OK;
+  } catch (const HipError& e) { g_last_error = e.what(); return AWRY_ERR_HIP;
+  } catch (const ArgError& e) { g_last_error = e.what(); return AWRY_ERR_ARG;
+  } catch (const QueryError& e) { g_last_error = e.what(); return AWRY_ERR_INVALID_QUERY;
+  } catch (const NoDeviceError& e) { g_last_error = e.what(); return AWRY_ERR_NO_DEVICE;
+  } catch (const std::bad_alloc&) { g_last_error = "out of host memory"; return AWRY_ERR_OOM;
+  } catch (const std::invalid_argument& e) { g_last_error = e.what(); return AWRY_ERR_FORMAT;
+  } catch (const std::exception& e) { g_last_error = e.what(); return AWRY_ERR_IO;
+  } catch (...) { g_last_error = "unknown error"; return AWRY_ERR_IO; }
+}
+
+template <class T>
+struct DevBuf {  // RAII device allocation on the current device
+  T* p = nullptr;
+  size_t n = 0;
+  DevBuf() = default;
+  explicit DevBuf(size_t count) { alloc(count); }
+  DevBuf(const DevBuf&) = delete;
+  DevBuf& operator=(const DevBuf&) = delete;
+  DevBuf(DevBuf&& o) noexcept : p(o.p), n(o.n) { o.p = nullptr; o.n = 0; }
+  DevBuf& operator=(DevBuf&& o) noexcept { reset(); p = o.p; n = o.n; o.p = nullptr; o.n = 0; return *this; }
+  ~DevBuf() { reset(); }
+  void alloc(size_t count) {
+    reset();
+    n = count;
+    if (count) {
+      hipError_t e = hipMalloc(reinterpret_cast<void**>(&p), count * sizeof(T));
+      if (e != hipSuccess) { p = nullptr; n = 0; throw HipError(std::string("hipMalloc failed: ") + hipGetErrorString(e)); }
+    }
+  }
+  void reset() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+};
+
+struct Replica {
+  int device = -1;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  DevBuf<uint64_t> blocks, sa_words, seq_starts;
+  DevBuf<SeedEntry> seed;
+  int seed_k = 0;
+  int num_cus = 256;
+  DevIndex dev{};
+  ~Replica() {
+    if (device >= 0) {
+      (void)hipSetDevice(device);
+      if (stream) (void)hipStreamDestroy(stream);
+      if (ev0) (void)hipEventDestroy(ev0);
+      if (ev1) (void)hipEventDestroy(ev1);
+      blocks.reset(); sa_words.reset(); seq_starts.reset(); seed.reset();
+    }
+  }
+};
+
+}  // namespace
+
+struct awry_index {
+  HostIndex host;
+  std::vector<std::unique_ptr<Replica>> reps;
+  int seed_k_request = -1;  // -1 = default policy
+};
+
+namespace {
+
+void require(bool ok, const char* msg) { if (!ok) throw ArgError(msg); }
+
+Replica& replica(awry_index* ix, int slot) {
+  require(ix != nullptr, "null index");
+  if (ix->reps.empty()) throw NoDeviceError("no device replica: call awry_set_devices() first (there is no CPU search path)");
+  require(slot >= 0 && slot < (int)ix->reps.size(), "replica slot out of range");
+  Replica& r = *ix->reps[slot];
+  HIP_CHECK(hipSetDevice(r.device));
+  return r;
+}
+
+int grid_for(const Replica& r, uint64_t work_items, int per_block, int blocks_per_cu = 8) {
+  uint64_t want = (work_items + per_block - 1) / per_block;
+  uint64_t cap = (uint64_t)r.num_cus * blocks_per_cu;
+  return (int)std::max<uint64_t>(1, std::min(want, cap));
+}
+
+bool narrow(const HostIndex& h) { return h.bwt_len < (1ull << 32) - 512; }
+
+int default_seed_k(const HostIndex& h) {
+  if (h.alphabet != NUCLEOTIDE || !narrow(h)) return 0;
+  if (const char* e = getenv("AWRY_SEED_K")) return std::max(0, std::min(16, atoi(e)));
+  int k = (int)std::floor(std::log((double)h.bwt_len) / std::log(4.0));
+  return std::max(1, std::min(k, 14));
+}
+
+// level-by-level seed table on the replica's device (see seed_extend_kernel)
+void build_seed(awry_index* ix, Replica& r, int k) {
+  r.seed.reset();
+  r.seed_k = 0;
+  r.dev.seed = nullptr;
+  r.dev.seed_k = 0;
+  if (k <= 0) return;
+  require(ix->host.alphabet == NUCLEOTIDE && narrow(ix->host), "seed table needs a nucleotide index with bwt_len < 2^32");
+  require(k <= 16, "seed k-mer length must be <= 16");
+  const uint64_t nfinal = 1ull << (2 * k);
+  DevBuf<SeedEntry> a(nfinal), b(std::max<uint64_t>(4, nfinal >> 2));
+  // level j lands in `a` when (k - j) is even, so the last level is in `a`
+  SeedEntry* cur = ((k - 1) % 2 == 0) ? a.p : b.p;
+  hipLaunchKernelGGL(seed_level1_kernel, dim3(1), dim3(256), 0, r.stream, r.dev, cur);
+  for (int j = 2; j <= k; j++) {
+    SeedEntry* nxt = ((k - j) % 2 == 0) ? a.p : b.p;
+    const uint64_t nchild = 1ull << (2 * j);
+    hipLaunchKernelGGL(seed_extend_kernel, dim3(grid_for(r, nchild * 4, 256)), dim3(256), 0, r.stream, r.dev, cur, nxt, nchild);
+    cur = nxt;
+  }
+  HIP_CHECK(hipGetLastError());
+  HIP_CHECK(hipStreamSynchronize(r.stream));
+  r.seed = std::move(a);
+  r.seed_k = k;
+  r.dev.seed = r.seed.p;
+  r.dev.seed_k = k;
+}
+
+std::unique_ptr<Replica> make_replica(awry_index* ix, int device) {
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev == 0) throw NoDeviceError("no HIP device available (there is no CPU search path)");
+  require(device >= 0 && device < ndev, "device id out of range");
+  HIP_CHECK(hipSetDevice(device));
+  auto r = std::make_unique<Replica>();
+  r->device = device;
+  hipDeviceProp_t prop;
+  HIP_CHECK(hipGetDeviceProperties(&prop, device));
+  r->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  HIP_CHECK(hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking));
+  HIP_CHECK(hipEventCreate(&r->ev0));
+  HIP_CHECK(hipEventCreate(&r->ev1));
+  const HostIndex& h = ix->host;
+  r->blocks.alloc(h.blocks.size());
+  r->sa_words.alloc(h.sa_words.size() + 1);  // +1: the straddle read of the last sample never leaves the buffer
+  r->seq_starts.alloc(std::max<size_t>(1, h.seq_starts.size()));
+  HIP_CHECK(hipMemcpy(r->blocks.p, h.blocks.data(), h.blocks.size() * 8, hipMemcpyHostToDevice));
+  HIP_CHECK(hipMemset(r->sa_words.p, 0, (h.sa_words.size() + 1) * 8));
+  if (!h.sa_words.empty()) HIP_CHECK(hipMemcpy(r->sa_words.p, h.sa_words.data(), h.sa_words.size() * 8, hipMemcpyHostToDevice));
+  if (!h.seq_starts.empty())
+    HIP_CHECK(hipMemcpy(r->seq_starts.p, h.seq_starts.data(), h.seq_starts.size() * 8, hipMemcpyHostToDevice));
+  DevIndex& d = r->dev;
+  d.blocks = r->blocks.p;
+  d.sa_words = r->sa_words.p;
+  d.seed = nullptr;
+  d.seq_starts = r->seq_starts.p;
+  d.nblocks = h.nblocks;
+  d.bwt_len = h.bwt_len;
+  d.sentinel_row = h.sentinel_row;
+  d.nseq = h.seq_starts.size();
+  for (int i = 0; i < 24; i++) d.prefix_sums[i] = i < (int)h.prefix_sums.size() ? h.prefix_sums[i] : 0;
+  d.sa_bits = (uint32_t)h.sa_bits;
+  d.sa_ratio = (uint32_t)h.sa_ratio;
+  d.alphabet = h.alphabet;
+  d.seed_k = 0;
+  build_seed(ix, *r, ix->seed_k_request < 0 ? default_seed_k(h) : ix->seed_k_request);
+  return r;
+}
+
+// ---- kernel launch helpers (all asynchronous on `s`) ------------------------------------------------
+
+void launch_count_ascii(Replica& r, const uint8_t* d_q, const uint64_t* d_off, uint64_t n, uint64_t* d_counts,
+                        uint64_t* d_ranges, uint8_t* d_status, hipStream_t s) {
+  if (n == 0) return;
+  const dim3 g(grid_for(r, n, 256)), b(256);
+  if (r.dev.alphabet == NUCLEOTIDE)
+    hipLaunchKernelGGL(count_scalar_kernel<NUCLEOTIDE>, g, b, 0, s, r.dev, d_q, d_off, n, d_counts, d_ranges, d_status);
+  else
+    hipLaunchKernelGGL(count_scalar_kernel<AMINO>, g, b, 0, s, r.dev, d_q, d_off, n, d_counts, d_ranges, d_status);
+  HIP_CHECK(hipGetLastError());
+}
+
+uint64_t scan_tiles(uint64_t n) { return (n + SCAN_TILE - 1) / SCAN_TILE; }
+
+void launch_scan(Replica& r, const uint64_t* d_counts, uint64_t n, uint64_t* d_hit_off, uint64_t* d_scratch, hipStream_t s) {
+  if (n == 0) { HIP_CHECK(hipMemsetAsync(d_hit_off, 0, 8, s)); return; }
+  const uint64_t tiles = scan_tiles(n);
+  hipLaunchKernelGGL(scan_tile_sums_kernel, dim3((unsigned)tiles), dim3(256), 0, s, d_counts, n, d_scratch);
+  hipLaunchKernelGGL(scan_tile_offsets_kernel, dim3(1), dim3(256), 0, s, d_scratch, tiles, d_scratch + tiles);
+  hipLaunchKernelGGL(scan_apply_kernel, dim3((unsigned)tiles), dim3(256), 0, s, d_counts, n, d_scratch, d_hit_off);
+  HIP_CHECK(hipGetLastError());
+}
+
+void launch_locate(Replica& r, const uint64_t* d_ranges, const uint64_t* d_hit_off, uint64_t n, uint64_t total,
+                   uint64_t* d_gpos, uint64_t* d_pos, hipStream_t s) {
+  if (total == 0) return;
+  const dim3 g(grid_for(r, total, 256)), b(256);
+  if (r.dev.alphabet == NUCLEOTIDE)
+    hipLaunchKernelGGL(locate_scalar_kernel<NUCLEOTIDE>, g, b, 0, s, r.dev, d_ranges, d_hit_off, n, total, d_gpos, d_pos);
+  else
+    hipLaunchKernelGGL(locate_scalar_kernel<AMINO>, g, b, 0, s, r.dev, d_ranges, d_hit_off, n, total, d_gpos, d_pos);
+  HIP_CHECK(hipGetLastError());
+}
+
+void launch_count_nt2(Replica& r, const uint64_t* d_words, uint64_t n, int L, uint64_t* d_counts, bool use_seed, hipStream_t s,
+                      unsigned long long* d_tally = nullptr) {
+  require(r.dev.alphabet == NUCLEOTIDE, "packed 2-bit queries need a nucleotide index");
+  require(r.dev.bwt_len < (1ull << 32) - 512, "the quad kernel needs bwt_len < 2^32");
+  require(L >= 1 && L <= 32, "packed k-mer length must be in 1..32");
+  if (n == 0) return;
+  const bool seeded = use_seed && r.seed_k > 0 && r.seed_k <= L;
+  const dim3 g(grid_for(r, n * 4, 256)), b(256);
+  if (d_tally) {
+    if (seeded) hipLaunchKernelGGL((count_nt2_quad_kernel<true, true>), g, b, 0, s, r.dev, d_words, n, L, d_counts, d_tally);
+    else hipLaunchKernelGGL((count_nt2_quad_kernel<false, true>), g, b, 0, s, r.dev, d_words, n, L, d_counts, d_tally);
+  } else {
+    if (seeded) hipLaunchKernelGGL((count_nt2_quad_kernel<true, false>), g, b, 0, s, r.dev, d_words, n, L, d_counts, d_tally);
+    else hipLaunchKernelGGL((count_nt2_quad_kernel<false, false>), g, b, 0, s, r.dev, d_words, n, L, d_counts, d_tally);
+  }
+  HIP_CHECK(hipGetLastError());
+}
+
+// ---- host batch drivers ----------------------------------------------------------------------------
+
+struct Shard { uint64_t lo, hi; };
+
+std::vector<Shard> shard_queries(uint64_t n, size_t parts) {  // query i -> replica floor(i * G / n): contiguous
+  std::vector<Shard> out(parts);
+  for (size_t g = 0; g < parts; g++) out[g] = Shard{n * g / parts, n * (g + 1) / parts};
+  return out;
+}
+
+// cut [lo, hi) into chunks bounded in queries and bytes
+std::vector<Shard> chunk_queries(const uint64_t* qoff, uint64_t lo, uint64_t hi) {
+  const uint64_t MAXQ = 1ull << 24, MAXB = 1ull << 29;
+  std::vector<Shard> out;
+  uint64_t a = lo;
+  while (a < hi) {
+    uint64_t b = std::min(hi, a + MAXQ);
+    while (b > a + 1 && qoff[b] - qoff[a] > MAXB) b = a + (b - a) / 2;
+    out.push_back(Shard{a, b});
+    a = b;
+  }
+  return out;
+}
+
+struct ChunkBuffers {
+  DevBuf<uint8_t> q, status;
+  DevBuf<uint64_t> off, counts, ranges;
+  std::vector<uint64_t> h_off;
+  std::vector<uint8_t> h_status;
+};
+
+// upload one chunk and run the generic count kernel; leaves counts / ranges / status on the device
+void run_count_chunk(Replica& r, ChunkBuffers& cb, const uint8_t* qbytes, const uint64_t* qoff, Shard c, bool want_ranges) {
+  const uint64_t n = c.hi - c.lo, base = qoff[c.lo], nbytes = qoff[c.hi] - base;
+  cb.h_off.resize(n + 1);
+  for (uint64_t i = 0; i <= n; i++) {
+    if (qoff[c.lo + i] < base || (i && qoff[c.lo + i] < qoff[c.lo + i - 1])) throw ArgError("query offsets must be non-decreasing");
+    cb.h_off[i] = qoff[c.lo + i] - base;
+  }
+  if (cb.q.n < nbytes + 1) cb.q.alloc(nbytes + 1);
+  if (cb.off.n < n + 1) cb.off.alloc(n + 1);
+  if (cb.counts.n < n) cb.counts.alloc(n);
+  if (cb.status.n < n) cb.status.alloc(n);
+  if (want_ranges && cb.ranges.n < 2 * n) cb.ranges.alloc(2 * n);
+  if (nbytes) HIP_CHECK(hipMemcpyAsync(cb.q.p, qbytes + base, nbytes, hipMemcpyHostToDevice, r.stream));
+  HIP_CHECK(hipMemcpyAsync(cb.off.p, cb.h_off.data(), (n + 1) * 8, hipMemcpyHostToDevice, r.stream));
+  launch_count_ascii(r, cb.q.p, cb.off.p, n, cb.counts.p, want_ranges ? cb.ranges.p : nullptr, cb.status.p, r.stream);
+  cb.h_status.resize(n);
+  HIP_CHECK(hipMemcpyAsync(cb.h_status.data(), cb.status.p, n, hipMemcpyDeviceToHost, r.stream));
+}
+
+void check_status(const ChunkBuffers& cb, uint64_t first_query) {
+  for (size_t i = 0; i < cb.h_status.size(); i++)
+    if (cb.h_status[i] != Q_OK) {
+      static const char* why[] = {"", "empty query", "query contains '$' or '#'", "query contains a non-ASCII byte"};
+      throw QueryError("query " + std::to_string(first_query + i) + ": " + why[cb.h_status[i] & 3] +
+                       " (undefined in the reference: src/fm_index.rs:406, src/bwt.rs:126-128)");
+    }
+}
+
+void count_shard(Replica& r, const uint8_t* qbytes, const uint64_t* qoff, Shard sh, uint64_t* counts_out) {
+  HIP_CHECK(hipSetDevice(r.device));
+  ChunkBuffers cb;
+  for (Shard c : chunk_queries(qoff, sh.lo, sh.hi)) {
+    run_count_chunk(r, cb, qbytes, qoff, c, false);
+    HIP_CHECK(hipMemcpyAsync(counts_out + c.lo, cb.counts.p, (c.hi - c.lo) * 8, hipMemcpyDeviceToHost, r.stream));
+    HIP_CHECK(hipStreamSynchronize(r.stream));
+    check_status(cb, c.lo);
+  }
+}
+
+struct LocateResult {  // per shard, rebased by the caller
+  std::vector<uint64_t> hit_counts, gpos;
+  std::vector<awry_pos_t> pos;
+};
+
+void locate_shard(Replica& r, const uint8_t* qbytes, const uint64_t* qoff, Shard sh, bool want_gpos, LocateResult& out) {
+  HIP_CHECK(hipSetDevice(r.device));
+  ChunkBuffers cb;
+  DevBuf<uint64_t> hit_off, scratch, d_gpos, d_pos;
+  out.hit_counts.resize(sh.hi - sh.lo);
+  for (Shard c : chunk_queries(qoff, sh.lo, sh.hi)) {
+    const uint64_t n = c.hi - c.lo;
+    run_count_chunk(r, cb, qbytes, qoff, c, true);
+    if (hit_off.n < n + 1) hit_off.alloc(n + 1);
+    const uint64_t sb = scan_tiles(n) + 1;
+    if (scratch.n < sb) scratch.alloc(sb);
+    launch_scan(r, cb.counts.p, n, hit_off.p, scratch.p, r.stream);
+    uint64_t total = 0;
+    HIP_CHECK(hipMemcpyAsync(&total, hit_off.p + n, 8, hipMemcpyDeviceToHost, r.stream));
+    HIP_CHECK(hipMemcpyAsync(out.hit_counts.data() + (c.lo - sh.lo), cb.counts.p, n * 8, hipMemcpyDeviceToHost, r.stream));
+    HIP_CHECK(hipStreamSynchronize(r.stream));
+    check_status(cb, c.lo);
+    if (total == 0) continue;
+    if (d_gpos.n < total) d_gpos.alloc(total);
+    if (d_pos.n < 2 * total) d_pos.alloc(2 * total);
+    launch_locate(r, cb.ranges.p, hit_off.p, n, total, d_gpos.p, d_pos.p, r.stream);
+    const size_t at = out.pos.size();
+    out.pos.resize(at + total);
+    HIP_CHECK(hipMemcpyAsync(out.pos.data() + at, d_pos.p, total * 16, hipMemcpyDeviceToHost, r.stream));
+    if (want_gpos) {
+      out.gpos.resize(at + total);
+      HIP_CHECK(hipMemcpyAsync(out.gpos.data() + at, d_gpos.p, total * 8, hipMemcpyDeviceToHost, r.stream));
+    }
+    HIP_CHECK(hipStreamSynchronize(r.stream));
+  }
+}
+
+// run fn(replica, shard, slot) on every replica concurrently; rethrow the first failure
+template <class F>
+void for_each_replica(awry_index* ix, uint64_t n, F&& fn) {
+  if (ix->reps.empty()) throw NoDeviceError("no device replica: call awry_set_devices() first (there is no CPU search path)");
+  auto shards = shard_queries(n, ix->reps.size());
+  if (ix->reps.size() == 1) { fn(*ix->reps[0], shards[0], 0); return; }
+  std::vector<std::exception_ptr> errs(ix->reps.size());
+  std::vector<std::thread> pool;
+  for (size_t g = 0; g < ix->reps.size(); g++)
+    pool.emplace_back([&, g] {
+      try { fn(*ix->reps[g], shards[g], (int)g); } catch (...) { errs[g] = std::current_exception(); }
+    });
+  for (auto& t : pool) t.join();
+  for (auto& e : errs) if (e) std::rethrow_exception(e);
+}
+
+template <class T>
+T* malloc_array(size_t n) {
+  T* p = static_cast<T*>(malloc(std::max<size_t>(1, n) * sizeof(T)));
+  if (!p) throw std::bad_alloc();
+  return p;
+}
+
+void fill_ref_kmer_table(awry_index* ix) {
+  HostIndex& h = ix->host;
+  const uint64_t nslots = ref_kmer_table_entries(h.alphabet, h.kmer_len);
+  if (h.ref_kmer_table.size() == 2 * nslots) return;
+  Replica& r = replica(ix, 0);
+  DevBuf<uint64_t> tab(2 * nslots);
+  const dim3 g(grid_for(r, nslots, 256)), b(256);
+  if (h.alphabet == NUCLEOTIDE)
+    hipLaunchKernelGGL(ref_kmer_table_kernel<NUCLEOTIDE>, g, b, 0, r.stream, r.dev, (int)h.kmer_len, nslots, tab.p);
+  else
+    hipLaunchKernelGGL(ref_kmer_table_kernel<AMINO>, g, b, 0, r.stream, r.dev, (int)h.kmer_len, nslots, tab.p);
+  HIP_CHECK(hipGetLastError());
+  h.ref_kmer_table.resize(2 * nslots);
+  HIP_CHECK(hipMemcpyAsync(h.ref_kmer_table.data(), tab.p, 2 * nslots * 8, hipMemcpyDeviceToHost, r.stream));
+  HIP_CHECK(hipStreamSynchronize(r.stream));
+}
+
+uint64_t scalar_op(awry_index* ix, int op, uint64_t a, uint64_t b, int idx, uint64_t* second = nullptr) {
+  Replica& r = replica(ix, 0);
+  DevBuf<uint64_t> out(2);
+  if (r.dev.alphabet == NUCLEOTIDE)
+    hipLaunchKernelGGL(scalar_ops_kernel<NUCLEOTIDE>, dim3(1), dim3(64), 0, r.stream, r.dev, op, a, b, idx, out.p);
+  else
+    hipLaunchKernelGGL(scalar_ops_kernel<AMINO>, dim3(1), dim3(64), 0, r.stream, r.dev, op, a, b, idx, out.p);
+  HIP_CHECK(hipGetLastError());
+  uint64_t h[2] = {0, 0};
+  HIP_CHECK(hipMemcpyAsync(h, out.p, 16, hipMemcpyDeviceToHost, r.stream));
+  HIP_CHECK(hipStreamSynchronize(r.stream));
+  if (second) *second = h[1];
+  return h[0];
+}
+
+int checked_symbol(const awry_index* ix, uint8_t ascii) {
+  if (ascii >= 0x80) throw QueryError("non-ASCII symbol");
+  return index_of_ascii(ix->host.alphabet, ascii);
+}
+
+}  // namespace
+
+// =====================================================================================================
+// C ABI
+// =====================================================================================================
+extern "C" {
+
+const char* awry_last_error(void) { return g_last_error.c_str(); }
+
+int awry_build_from_text(const uint8_t* text, uint64_t bwt_len, int alphabet, uint64_t sa_ratio, uint8_t kmer_len,
+                         const uint64_t* seq_starts, const char* const* headers, uint64_t nseq, awry_index_t** out) {
+  return guarded([&] {
+    require(text && out && bwt_len > 0, "null argument");
+    require(alphabet == NUCLEOTIDE || alphabet == AMINO, "bad alphabet id");
+    static const uint64_t zero = 0;
+    if (nseq == 0 || !seq_starts) { seq_starts = &zero; nseq = 1; headers = nullptr; }
+    auto ix = std::make_unique<awry_index>();
+    build_from_text(ix->host, text, bwt_len, alphabet, sa_ratio, kmer_len, seq_starts, headers, nseq);
+    *out = ix.release();
+  });
+}
+
+int awry_build(const awry_build_args_t* args, awry_index_t** out) {
+  return guarded([&] {
+    require(args && args->input_path && out, "null argument");
+    require(args->alphabet <= 1, "bad alphabet id");
+    SequenceFile sf = read_sequence_file(args->input_path, args->alphabet);
+    std::vector<const char*> hdr;
+    for (auto& h : sf.headers) hdr.push_back(h.c_str());
+    auto ix = std::make_unique<awry_index>();
+    build_from_text(ix->host, sf.text.data(), sf.text.size(), args->alphabet, args->sa_ratio, args->kmer_len,
+                    sf.starts.data(), hdr.data(), sf.starts.size());
+    *out = ix.release();
+  });
+}
+
+int awry_load(const char* path, awry_index_t** out) {
+  return guarded([&] {
+    require(path && out, "null argument");
+    auto ix = std::make_unique<awry_index>();
+    load_awry(ix->host, path);
+    *out = ix.release();
+  });
+}
+
+int awry_save(awry_index_t* idx, const char* path) {
+  return guarded([&] {
+    require(idx && path, "null argument");
+    fill_ref_kmer_table(idx);
+    save_awry(idx->host, path);
+  });
+}
+
+void awry_free(awry_index_t* idx) { delete idx; }
+
+int awry_set_devices(awry_index_t* idx, const int* device_ids, int n_devices) {
+  return guarded([&] {
+    require(idx != nullptr, "null index");
+    if (n_devices <= 0 || !device_ids) throw NoDeviceError("awry_set_devices needs at least one GPU: there is no CPU search path");
+    std::vector<std::unique_ptr<Replica>> reps;
+    for (int i = 0; i < n_devices; i++) reps.push_back(make_replica(idx, device_ids[i]));
+    idx->reps = std::move(reps);
+  });
+}
+
+int awry_set_seed_kmer_len(awry_index_t* idx, int k) {
+  return guarded([&] {
+    require(idx != nullptr, "null index");
+    require(k >= -1 && k <= 16, "seed k-mer length must be in -1..16");
+    idx->seed_k_request = k;
+    for (size_t s = 0; s < idx->reps.size(); s++) {
+      Replica& r = replica(idx, (int)s);
+      build_seed(idx, r, k < 0 ? default_seed_k(idx->host) : k);
+    }
+  });
+}
+
+int awry_seed_kmer_len(const awry_index_t* idx) { return idx && !idx->reps.empty() ? idx->reps[0]->seed_k : 0; }
+int awry_num_devices(const awry_index_t* idx) { return idx ? (int)idx->reps.size() : 0; }
+int awry_replica_device(const awry_index_t* idx, int slot) {
+  return idx && slot >= 0 && slot < (int)idx->reps.size() ? idx->reps[slot]->device : -1;
+}
+
+int awry_count_batch(awry_index_t* idx, const uint8_t* qbytes, const uint64_t* qoff, uint64_t n, uint64_t* counts_out) {
+  return guarded([&] {
+    require(idx && qoff && (counts_out || n == 0), "null argument");
+    require(qbytes || qoff[n] == qoff[0], "null query bytes");
+    for_each_replica(idx, n, [&](Replica& r, Shard sh, int) { count_shard(r, qbytes, qoff, sh, counts_out); });
+  });
+}
+
+int awry_locate_batch(awry_index_t* idx, const uint8_t* qbytes, const uint64_t* qoff, uint64_t n, uint64_t** hit_off_out,
+                      awry_pos_t** hits_out, uint64_t** global_pos_out) {
+  return guarded([&] {
+    require(idx && qoff && hit_off_out && hits_out, "null argument");
+    require(qbytes || qoff[n] == qoff[0], "null query bytes");
+    std::vector<LocateResult> res(std::max<size_t>(1, idx->reps.size()));
+    for_each_replica(idx, n, [&](Replica& r, Shard sh, int g) { locate_shard(r, qbytes, qoff, sh, global_pos_out != nullptr, res[g]); });
+    uint64_t total = 0;
+    for (auto& x : res) total += x.pos.size();
+    std::unique_ptr<uint64_t, decltype(&free)> off(malloc_array<uint64_t>(n + 1), &free);
+    std::unique_ptr<awry_pos_t, decltype(&free)> hits(malloc_array<awry_pos_t>(total), &free);
+    std::unique_ptr<uint64_t, decltype(&free)> gp(global_pos_out ? malloc_array<uint64_t>(total) : nullptr, &free);
+    uint64_t qi = 0, at = 0;
+    off.get()[0] = 0;
+    for (auto& x : res) {  // shards are contiguous in query order, so concatenation keeps input order
+      for (uint64_t c : x.hit_counts) { off.get()[qi + 1] = off.get()[qi] + c; qi++; }
+      if (!x.pos.empty()) memcpy(hits.get() + at, x.pos.data(), x.pos.size() * sizeof(awry_pos_t));
+      if (gp && !x.gpos.empty()) memcpy(gp.get() + at, x.gpos.data(), x.gpos.size() * 8);
+      at += x.pos.size();
+    }
+    *hit_off_out = off.release();
+    *hits_out = hits.release();
+    if (global_pos_out) *global_pos_out = gp.release();
+  });
+}
+
+void awry_free_buffer(void* p) { free(p); }
+
+int awry_count(awry_index_t* idx, const uint8_t* q, uint64_t len, uint64_t* count) {
+  const uint64_t off[2] = {0, len};
+  return awry_count_batch(idx, q, off, 1, count);
+}
+
+int awry_search_range(awry_index_t* idx, const uint8_t* q, uint64_t len, awry_range_t* out) {
+  return guarded([&] {
+    require(idx && out && (q || len == 0), "null argument");
+    Replica& r = replica(idx, 0);
+    ChunkBuffers cb;
+    const uint64_t off[2] = {0, len};
+    run_count_chunk(r, cb, q, off, Shard{0, 1}, true);
+    uint64_t h[2];
+    HIP_CHECK(hipMemcpyAsync(h, cb.ranges.p, 16, hipMemcpyDeviceToHost, r.stream));
+    HIP_CHECK(hipStreamSynchronize(r.stream));
+    check_status(cb, 0);
+    out->start_ptr = h[0];
+    out->end_ptr = h[1];
+  });
+}
+
+int awry_locate(awry_index_t* idx, const uint8_t* q, uint64_t len, awry_pos_t** hits_out, uint64_t** global_pos_out,
+                uint64_t* n_hits) {
+  const uint64_t off[2] = {0, len};
+  uint64_t* hit_off = nullptr;
+  int rc = awry_locate_batch(idx, q, off, 1, &hit_off, hits_out, global_pos_out);
+  if (rc == AWRY_OK) {
+    if (n_hits) *n_hits = hit_off[1];
+    free(hit_off);
+  }
+  return rc;
+}
+
+int awry_initial_range(const awry_index_t* idx, uint8_t symbol_ascii, awry_range_t* out) {
+  return guarded([&] {
+    require(idx && out, "null argument");
+    int s = checked_symbol(idx, symbol_ascii);
+    out->start_ptr = idx->host.prefix_sums[s];           // src/search.rs:43-48
+    out->end_ptr = idx->host.prefix_sums[s + 1] - 1;
+  });
+}
+
+int awry_update_range(awry_index_t* idx, awry_range_t in, uint8_t symbol_ascii, awry_range_t* out) {
+  return guarded([&] {
+    require(idx && out, "null argument");
+    int s = checked_symbol(idx, symbol_ascii);
+    if (s == 0) throw QueryError("cannot extend a range with the sentinel (src/bwt.rs:126-128 panics)");
+    if (in.start_ptr == 0 || in.start_ptr > idx->host.bwt_len || in.end_ptr >= idx->host.bwt_len)
+      throw ArgError("range outside the BWT");
+    out->start_ptr = scalar_op(idx, 0, in.start_ptr, in.end_ptr, s, &out->end_ptr);
+  });
+}
+
+int awry_backstep(awry_index_t* idx, uint64_t row, uint64_t* out) {
+  return guarded([&] {
+    require(idx && out, "null argument");
+    require(row < idx->host.bwt_len, "row outside the BWT");
+    *out = scalar_op(idx, 1, row, 0, 0);
+  });
+}
+
+int awry_get_seq_location(const awry_index_t* idx, uint64_t g, awry_pos_t* out) {
+  return guarded([&] {
+    require(idx && out, "null argument");
+    const auto& st = idx->host.seq_starts;
+    require(!st.empty(), "index has no sequence records");
+    size_t i = (size_t)(std::upper_bound(st.begin(), st.end(), g) - st.begin());
+    i = i ? i - 1 : 0;
+    out->seq_idx = i;
+    out->local_pos = g - st[i];
+  });
+}
+
+int awry_alphabet(const awry_index_t* idx) { return idx ? idx->host.alphabet : -1; }
+uint64_t awry_bwt_len(const awry_index_t* idx) { return idx ? idx->host.bwt_len : 0; }
+uint64_t awry_version(const awry_index_t* idx) { return idx ? idx->host.version : 0; }
+uint64_t awry_sa_ratio(const awry_index_t* idx) { return idx ? idx->host.sa_ratio : 0; }
+uint8_t awry_kmer_len(const awry_index_t* idx) { return idx ? idx->host.kmer_len : 0; }
+uint64_t awry_sentinel_row(const awry_index_t* idx) { return idx ? idx->host.sentinel_row : 0; }
+const uint64_t* awry_prefix_sums(const awry_index_t* idx, uint64_t* len) {
+  if (!idx) return nullptr;
+  if (len) *len = idx->host.prefix_sums.size();
+  return idx->host.prefix_sums.data();
+}
+uint64_t awry_num_sequences(const awry_index_t* idx) { return idx ? idx->host.seq_starts.size() : 0; }
+uint64_t awry_sequence_start(const awry_index_t* idx, uint64_t i) {
+  return idx && i < idx->host.seq_starts.size() ? idx->host.seq_starts[i] : 0;
+}
+const char* awry_sequence_header(const awry_index_t* idx, uint64_t i) {
+  return idx && i < idx->host.headers.size() ? idx->host.headers[i].c_str() : nullptr;
+}
+const uint64_t* awry_block_words(const awry_index_t* idx, uint64_t* nwords) {
+  if (!idx) return nullptr;
+  if (nwords) *nwords = idx->host.blocks.size();
+  return idx->host.blocks.data();
+}
+const uint64_t* awry_sa_words(const awry_index_t* idx, uint64_t* nwords) {
+  if (!idx) return nullptr;
+  if (nwords) *nwords = idx->host.sa_words.size();
+  return idx->host.sa_words.data();
+}
+int awry_block_reference_layout(const awry_index_t* idx, uint64_t block, uint64_t* out, uint64_t out_words) {
+  return guarded([&] {
+    require(idx && out, "null argument");
+    require(block < idx->host.nblocks, "block out of range");
+    const uint64_t need = 4 * num_planes(idx->host.alphabet) + (idx->host.alphabet == NUCLEOTIDE ? 8 : 24);
+    require(out_words >= need, "output buffer too small");
+    block_to_reference(idx->host, block, out);
+  });
+}
+
+int awry_host_suffix_array(const uint8_t* text, uint64_t n, uint64_t* sa_out) {
+  return guarded([&] {
+    require(text && sa_out, "null argument");
+    suffix_array_bytes(text, n, sa_out);
+  });
+}
+uint8_t awry_symbol_index(int alphabet, uint8_t ascii) { return (uint8_t)index_of_ascii(alphabet, ascii); }
+
+// ---- device-resident API -----------------------------------------------------------------------------
+
+int awry_dev_pack_nt2(awry_index_t* idx, int slot, const void* d_ascii, uint64_t n, int L, void* d_words, void* d_bad, void* stream) {
+  return guarded([&] {
+    Replica& r = replica(idx, slot);
+    require(L >= 1 && L <= 32, "packed k-mer length must be in 1..32");
+    require(d_ascii && d_words && d_bad, "null device pointer");
+    if (n == 0) return;
+    hipLaunchKernelGGL(pack_nt2_kernel, dim3(grid_for(r, n, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const uint8_t*)d_ascii, n, L, (uint64_t*)d_words, (unsigned long long*)d_bad);
+    HIP_CHECK(hipGetLastError());
+  });
+}
+
+int awry_dev_count_nt2(awry_index_t* idx, int slot, const void* d_words, uint64_t n, int L, void* d_counts, int use_seed, void* stream) {
+  return guarded([&] {
+    Replica& r = replica(idx, slot);
+    require((d_words && d_counts) || n == 0, "null device pointer");
+    launch_count_nt2(r, (const uint64_t*)d_words, n, L, (uint64_t*)d_counts, use_seed != 0, (hipStream_t)stream);
+  });
+}
+
+int awry_dev_count_nt2_tally(awry_index_t* idx, int slot, const void* d_words, uint64_t n, int L, void* d_counts, int use_seed,
+                             void* d_tally, void* stream) {
+  return guarded([&] {
+    Replica& r = replica(idx, slot);
+    require((d_words && d_counts && d_tally) || n == 0, "null device pointer");
+    launch_count_nt2(r, (const uint64_t*)d_words, n, L, (uint64_t*)d_counts, use_seed != 0, (hipStream_t)stream,
+                     (unsigned long long*)d_tally);
+  });
+}
+
+int awry_dev_count_ascii(awry_index_t* idx, int slot, const void* d_qbytes, const void* d_qoff, uint64_t n, void* d_counts,
+                         void* d_ranges, void* d_status, void* stream) {
+  return guarded([&] {
+    Replica& r = replica(idx, slot);
+    require((d_qoff && d_counts) || n == 0, "null device pointer");
+    launch_count_ascii(r, (const uint8_t*)d_qbytes, (const uint64_t*)d_qoff, n, (uint64_t*)d_counts, (uint64_t*)d_ranges,
+                       (uint8_t*)d_status, (hipStream_t)stream);
+  });
+}
+
+uint64_t awry_dev_scan_scratch_bytes(uint64_t n) { return (scan_tiles(n) + 1) * 8; }
+
+int awry_dev_scan_counts(awry_index_t* idx, int slot, const void* d_counts, uint64_t n, void* d_hit_off, void* d_scratch, void* stream) {
+  return guarded([&] {
+    Replica& r = replica(idx, slot);
+    require(d_hit_off && ((d_counts && d_scratch) || n == 0), "null device pointer");
+    launch_scan(r, (const uint64_t*)d_counts, n, (uint64_t*)d_hit_off, (uint64_t*)d_scratch, (hipStream_t)stream);
+  });
+}
+
+int awry_dev_locate(awry_index_t* idx, int slot, const void* d_ranges, const void* d_hit_off, uint64_t n, uint64_t total,
+                    void* d_global_pos, void* d_pos, void* stream) {
+  return guarded([&] {
+    Replica& r = replica(idx, slot);
+    require((d_ranges && d_hit_off && d_global_pos) || total == 0, "null device pointer");
+    launch_locate(r, (const uint64_t*)d_ranges, (const uint64_t*)d_hit_off, n, total, (uint64_t*)d_global_pos, (uint64_t*)d_pos,
+                  (hipStream_t)stream);
+  });
+}
+
+int awry_dev_malloc(awry_index_t* idx, int slot, uint64_t bytes, void** d_out) {
+  return guarded([&] { replica(idx, slot); require(d_out != nullptr, "null argument"); HIP_CHECK(hipMalloc(d_out, std::max<uint64_t>(bytes, 8))); });
+}
+int awry_dev_free(awry_index_t* idx, int slot, void* d) {
+  return guarded([&] { replica(idx, slot); if (d) HIP_CHECK(hipFree(d)); });
+}
+int awry_dev_memcpy_h2d(awry_index_t* idx, int slot, void* d_dst, const void* h_src, uint64_t bytes) {
+  return guarded([&] { replica(idx, slot); if (bytes) HIP_CHECK(hipMemcpy(d_dst, h_src, bytes, hipMemcpyHostToDevice)); });
+}
+int awry_dev_memcpy_d2h(awry_index_t* idx, int slot, void* h_dst, const void* d_src, uint64_t bytes) {
+  return guarded([&] { replica(idx, slot); if (bytes) HIP_CHECK(hipMemcpy(h_dst, d_src, bytes, hipMemcpyDeviceToHost)); });
+}
+int awry_dev_memset(awry_index_t* idx, int slot, void* d_dst, int value, uint64_t bytes) {
+  return guarded([&] { replica(idx, slot); if (bytes) HIP_CHECK(hipMemset(d_dst, value, bytes)); });
+}
+int awry_dev_synchronize(awry_index_t* idx, int slot) {
+  return guarded([&] { replica(idx, slot); HIP_CHECK(hipDeviceSynchronize()); });
+}
+int awry_dev_timer_begin(awry_index_t* idx, int slot, void* stream) {
+  return guarded([&] { Replica& r = replica(idx, slot); HIP_CHECK(hipEventRecord(r.ev0, (hipStream_t)stream)); });
+}
+int awry_dev_timer_end(awry_index_t* idx, int slot, void* stream, float* ms_out) {
+  return guarded([&] {
+    Replica& r = replica(idx, slot);
+    require(ms_out != nullptr, "null argument");
+    HIP_CHECK(hipEventRecord(r.ev1, (hipStream_t)stream));
+    HIP_CHECK(hipEventSynchronize(r.ev1));
+    HIP_CHECK(hipEventElapsedTime(ms_out, r.ev0, r.ev1));
+  });
+}
+
+}  // extern "C"

@@ -1,0 +1,359 @@
+// host_index.cpp -- host-side index construction, sequence-file reader and .awry v1 (de)serialisation.
+#include "host_index.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <stdexcept>
+#include <thread>
+
+#include "alphabet.h"
+#include "sais.hpp"
+
+namespace awry {
+
+// src/compressed_suffix_array.rs:124-130
+uint64_t csa_bits_per_element(uint64_t bwt_len) {
+  uint64_t largest = bwt_len - 1;
+  return largest == 0 ? 0 : 64 - (uint64_t)__builtin_clzll(largest);
+}
+// src/compressed_suffix_array.rs:113-123
+uint64_t csa_word_len(uint64_t bwt_len, uint64_t ratio) {
+  unsigned __int128 bits = (unsigned __int128)((bwt_len + ratio - 1) / ratio) * csa_bits_per_element(bwt_len);
+  return (uint64_t)((bits + 63) / 64);
+}
+// src/kmer_lookup_table.rs:113-118
+uint64_t ref_kmer_table_entries(int alphabet, unsigned kmer_len) {
+  uint64_t sigma = (uint64_t)cardinality(alphabet) - 2, n = 1;
+  for (unsigned i = 0; i < kmer_len; i++) {
+    if (n > (1ull << 40) / sigma) throw std::runtime_error("k-mer table too large");
+    n *= sigma;
+  }
+  return n;
+}
+
+// ------------------------------------------------------------------ sequence files
+
+static std::string first_token(const char* p, size_t n) {
+  size_t k = 0;
+  while (k < n && !isspace((unsigned char)p[k])) k++;
+  return std::string(p, k);
+}
+
+// Text model of src/fm_index.rs:148-153,182,220-223: records joined by one delimiter byte ('N' / 'X'),
+// one trailing '$'.  The reader itself (libsufr::util::read_sequence_file) is not in the reference tree;
+// letters are upper-cased (ignore_softmask: true, src/fm_index.rs:161) and the header is the first
+// whitespace-delimited token.  Parity is pinned only for upper-case canonical letters.
+SequenceFile read_sequence_file(const std::string& path, int alphabet) {
+  std::ifstream in(path, std::ios::binary);
+  if (!in) throw std::runtime_error("cannot open sequence file: " + path);
+  SequenceFile sf;
+  const uint8_t delim = alphabet == NUCLEOTIDE ? 'N' : 'X';
+  std::string line;
+  bool first = true, fastq = false;
+  int state = 0;  // fastq: 0 header, 1 sequence, 2 '+', 3 quality
+  while (std::getline(in, line)) {
+    while (!line.empty() && (line.back() == '\r' || line.back() == '\n')) line.pop_back();
+    if (first && !line.empty()) { fastq = line[0] == '@'; first = false; }
+    bool is_header = fastq ? state == 0 : (!line.empty() && line[0] == '>');
+    if (is_header) {
+      if (line.empty()) continue;
+      if (!sf.starts.empty()) sf.text.push_back(delim);
+      sf.starts.push_back(sf.text.size());
+      sf.headers.push_back(first_token(line.data() + 1, line.size() - 1));
+      if (fastq) state = 1;
+      continue;
+    }
+    if (fastq && state == 2) { state = 3; continue; }
+    if (fastq && state == 3) { state = 0; continue; }
+    if (sf.starts.empty() && !line.empty()) {  // sequence data before any header
+      sf.starts.push_back(0);
+      sf.headers.emplace_back("");
+    }
+    for (char c : line)
+      if (!isspace((unsigned char)c)) sf.text.push_back((uint8_t)toupper((unsigned char)c));
+    if (fastq) state = 2;
+  }
+  if (sf.starts.empty()) throw std::runtime_error("no sequence records in " + path);
+  sf.text.push_back('$');
+  return sf;
+}
+
+// ------------------------------------------------------------------ packing
+
+namespace {
+
+inline void set_symbol(uint64_t* blk, int alphabet, uint32_t code, unsigned pos) {
+  const int l = (int)(pos >> 6);
+  const uint64_t bit = 1ull << (pos & 63);
+  for (int b = 0; code; b++, code >>= 1)
+    if (code & 1) blk[plane_word(alphabet, b, l)] |= bit;
+}
+
+inline void set_milestones(uint64_t* blk, int alphabet, const uint64_t* counts) {
+  if (alphabet == NUCLEOTIDE) {
+    for (int l = 0; l < 4; l++) blk[nt_ms_word(l)] = counts[nt_index_of_letter(l)];
+  } else {
+    for (int t = 0; t < 21; t++) {
+      uint64_t v = counts[t + 1] & 0xffffffffull;
+      blk[aa_ms_word(t)] |= v << (32 * aa_ms_half(t));
+    }
+  }
+}
+
+unsigned worker_count(uint64_t items, uint64_t min_per_thread) {
+  unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+  uint64_t want = std::max<uint64_t>(1, items / std::max<uint64_t>(1, min_per_thread));
+  return (unsigned)std::min<uint64_t>(std::min(hw, 32u), want);
+}
+
+template <class F>
+void parallel_ranges(uint64_t n, uint64_t align, unsigned threads, F&& fn) {
+  if (threads <= 1 || n == 0) { fn(0, 0, n); return; }
+  uint64_t per = ((n + threads - 1) / threads + align - 1) / align * align;
+  std::vector<std::thread> pool;
+  for (unsigned t = 0; t < threads; t++) {
+    uint64_t lo = std::min(n, per * t), hi = std::min(n, per * (t + 1));
+    pool.emplace_back([=, &fn] { fn(t, lo, hi); });
+  }
+  for (auto& th : pool) th.join();
+}
+
+}  // namespace
+
+void pack_index(HostIndex& ix, const uint8_t* text, uint64_t bwt_len, const uint64_t* sa64, const uint32_t* sa32) {
+  const int A = ix.alphabet, card = cardinality(A), BW = block_words(A);
+  if (A == AMINO && bwt_len >= (1ull << 32))
+    throw std::runtime_error("amino indexes with bwt_len >= 2^32 are not supported (u32 milestones)");
+  ix.bwt_len = bwt_len;
+  ix.nblocks = (bwt_len + 255) / 256;  // src/bwt.rs:302-304
+  ix.sa_bits = csa_bits_per_element(bwt_len);
+  ix.blocks.assign(ix.nblocks * BW, 0);
+  ix.sa_words.assign(csa_word_len(bwt_len, ix.sa_ratio), 0);
+  auto SA = [&](uint64_t i) -> uint64_t { return sa32 ? (uint64_t)sa32[i] : sa64[i]; };
+  auto prev_char = [&](uint64_t v) -> uint8_t { return v == 0 ? (uint8_t)'$' : text[v - 1]; };
+
+  // pass 1: letter histogram per chunk -> exclusive counts at each chunk start
+  const unsigned T = worker_count(bwt_len, 1u << 20);
+  std::vector<std::vector<uint64_t>> hist(T, std::vector<uint64_t>(24, 0));
+  std::vector<uint64_t> lo_of(T, 0), hi_of(T, 0);
+  std::vector<uint64_t> sentinel(T, UINT64_MAX);
+  parallel_ranges(bwt_len, 256, T, [&](unsigned t, uint64_t lo, uint64_t hi) {
+    lo_of[t] = lo; hi_of[t] = hi;
+    auto& h = hist[t];
+    for (uint64_t i = lo; i < hi; i++) {
+      uint64_t v = SA(i);
+      if (v == 0) sentinel[t] = i;
+      h[index_of_ascii(A, prev_char(v))]++;
+    }
+  });
+  std::vector<std::vector<uint64_t>> base(T, std::vector<uint64_t>(24, 0));
+  std::vector<uint64_t> total(24, 0);
+  for (unsigned t = 0; t < T; t++) {
+    base[t] = total;
+    for (int c = 0; c < 24; c++) total[c] += hist[t][c];
+    if (sentinel[t] != UINT64_MAX) ix.sentinel_row = sentinel[t];
+  }
+  // pass 2: planes + milestones (src/fm_index.rs:203-230)
+  parallel_ranges(bwt_len, 256, T, [&](unsigned t, uint64_t lo, uint64_t hi) {
+    std::vector<uint64_t> counts = base[t];
+    for (uint64_t i = lo; i < hi; i++) {
+      uint64_t* blk = ix.blocks.data() + (i >> 8) * BW;
+      if ((i & 255) == 0) set_milestones(blk, A, counts.data());
+      int idx = index_of_ascii(A, prev_char(SA(i)));
+      set_symbol(blk, A, code_of_index(A, idx), (unsigned)(i & 255));
+      counts[idx]++;
+    }
+  });
+  // prefix sums (src/fm_index.rs:233-240)
+  ix.prefix_sums.assign(card + 1, 0);
+  uint64_t acc = 0;
+  for (int i = 0; i <= card; i++) {
+    ix.prefix_sums[i] = acc;
+    if (i != card) acc += total[i];
+  }
+  // sampled SA, bit-packed LSB-first (src/compressed_suffix_array.rs:51-64); each worker owns a word range
+  const uint64_t bits = ix.sa_bits, nsamp = (bwt_len + ix.sa_ratio - 1) / ix.sa_ratio, nw = ix.sa_words.size();
+  if (bits)
+    parallel_ranges(nw, 1, worker_count(nw, 1u << 18), [&](unsigned, uint64_t w0, uint64_t w1) {
+      if (w0 >= w1) return;
+      uint64_t j0 = (uint64_t)(((unsigned __int128)w0 * 64) / bits);
+      uint64_t j1 = std::min<uint64_t>(nsamp, (uint64_t)(((unsigned __int128)w1 * 64 + bits - 1) / bits));
+      for (uint64_t j = j0; j < j1; j++) {
+        uint64_t v = SA(j * ix.sa_ratio);
+        unsigned __int128 off = (unsigned __int128)j * bits;
+        uint64_t w = (uint64_t)(off / 64), b = (uint64_t)(off % 64);
+        if (w >= w0 && w < w1) ix.sa_words[w] |= v << b;
+        if (b + bits > 64 && w + 1 >= w0 && w + 1 < w1) ix.sa_words[w + 1] |= v >> (64 - b);
+      }
+    });
+}
+
+void build_from_text(HostIndex& ix, const uint8_t* text, uint64_t bwt_len, int alphabet, uint64_t sa_ratio,
+                     unsigned kmer_len, const uint64_t* seq_starts, const char* const* headers, uint64_t nseq) {
+  if (bwt_len == 0 || text[bwt_len - 1] != '$') throw std::runtime_error("text must end with '$'");
+  if (alphabet != NUCLEOTIDE && alphabet != AMINO) throw std::runtime_error("bad alphabet id");
+  ix.alphabet = alphabet;
+  ix.sa_ratio = sa_ratio ? sa_ratio : 8;                                     // src/fm_index.rs:122
+  ix.kmer_len = (uint8_t)(kmer_len ? kmer_len : (alphabet == NUCLEOTIDE ? 10 : 4));  // src/kmer_lookup_table.rs:23-24
+  ref_kmer_table_entries(alphabet, ix.kmer_len);                            // range check
+  ix.seq_starts.assign(seq_starts, seq_starts + nseq);
+  ix.headers.clear();
+  for (uint64_t i = 0; i < nseq; i++) ix.headers.emplace_back(headers && headers[i] ? headers[i] : "");
+  ix.ref_kmer_table.clear();
+  if (bwt_len < (1ull << 31)) {
+    std::vector<int32_t> sa((size_t)bwt_len);
+    sais_rec<uint8_t, int32_t>(text, sa.data(), (int32_t)bwt_len, 255);
+    pack_index(ix, text, bwt_len, nullptr, reinterpret_cast<const uint32_t*>(sa.data()));
+  } else {
+    std::vector<uint64_t> sa((size_t)bwt_len);
+    suffix_array_bytes(text, bwt_len, sa.data());
+    pack_index(ix, text, bwt_len, sa.data(), nullptr);
+  }
+}
+
+// ------------------------------------------------------------------ reference layout <-> device layout
+
+void block_to_reference(const HostIndex& ix, uint64_t b, uint64_t* out) {
+  const int A = ix.alphabet, P = num_planes(A), BW = block_words(A);
+  const uint64_t* blk = ix.blocks.data() + b * BW;
+  for (int p = 0; p < P; p++)
+    for (int l = 0; l < 4; l++) out[4 * p + l] = blk[plane_word(A, p, l)];
+  uint64_t* ms = out + 4 * P;
+  const int nms = A == NUCLEOTIDE ? 8 : 24;  // src/bwt.rs:29,139
+  std::fill(ms, ms + nms, 0);
+  const uint64_t dollar = ix.sentinel_row < 256 * b ? 1 : 0;  // '$' occurs exactly once
+  ms[0] = dollar;
+  if (A == NUCLEOTIDE) {
+    uint64_t sum = 0;
+    for (int l = 0; l < 4; l++) { ms[nt_index_of_letter(l)] = blk[nt_ms_word(l)]; sum += blk[nt_ms_word(l)]; }
+    ms[4] = 256 * b - sum - dollar;  // N
+  } else {
+    for (int t = 0; t < 21; t++) ms[t + 1] = (blk[aa_ms_word(t)] >> (32 * aa_ms_half(t))) & 0xffffffffull;
+  }
+}
+
+void block_from_reference(HostIndex& ix, uint64_t b, const uint64_t* in) {
+  const int A = ix.alphabet, P = num_planes(A), BW = block_words(A);
+  uint64_t* blk = ix.blocks.data() + b * BW;
+  std::fill(blk, blk + BW, 0);
+  for (int p = 0; p < P; p++)
+    for (int l = 0; l < 4; l++) blk[plane_word(A, p, l)] = in[4 * p + l];
+  set_milestones(blk, A, in + 4 * P);
+}
+
+// ------------------------------------------------------------------ .awry v1
+
+static const char MAGIC[12] = "AWRY-Index\n";  // 11 bytes on disk, src/fm_index_file.rs:18
+
+namespace {
+struct Writer {
+  FILE* f;
+  void put(const void* p, size_t n) { if (n && fwrite(p, 1, n, f) != n) throw std::runtime_error("short write"); }
+  void u64(uint64_t v) { put(&v, 8); }
+};
+struct Reader {
+  FILE* f;
+  void get(void* p, size_t n) { if (n && fread(p, 1, n, f) != n) throw std::runtime_error("truncated .awry file"); }
+  uint64_t u64() { uint64_t v; get(&v, 8); return v; }
+};
+struct FileCloser { FILE* f; ~FileCloser() { if (f) fclose(f); } };
+}  // namespace
+
+// src/fm_index_file.rs:42-106, src/sequence_index.rs:144-152
+void save_awry(const HostIndex& ix, const std::string& path) {
+  const uint64_t nk = ref_kmer_table_entries(ix.alphabet, ix.kmer_len);
+  if (ix.ref_kmer_table.size() != 2 * nk) throw std::runtime_error("k-mer table not materialised before save");
+  FILE* f = fopen(path.c_str(), "wb");
+  if (!f) throw std::runtime_error("cannot open for writing: " + path);
+  FileCloser fc{f};
+  Writer w{f};
+  w.put(MAGIC, 11);
+  w.u64(ix.version); w.u64(ix.sa_ratio); w.u64(ix.bwt_len); w.u64((uint64_t)ix.alphabet);  // :165-181
+  const int RW = 4 * num_planes(ix.alphabet) + (ix.alphabet == NUCLEOTIDE ? 8 : 24);
+  std::vector<uint64_t> buf((size_t)RW * 4096);
+  for (uint64_t b0 = 0; b0 < ix.nblocks; b0 += 4096) {
+    uint64_t nb = std::min<uint64_t>(4096, ix.nblocks - b0);
+    for (uint64_t j = 0; j < nb; j++) block_to_reference(ix, b0 + j, buf.data() + j * RW);
+    w.put(buf.data(), nb * RW * 8);
+  }
+  w.put(ix.prefix_sums.data(), ix.prefix_sums.size() * 8);
+  w.put(ix.sa_words.data(), ix.sa_words.size() * 8);
+  w.put(&ix.kmer_len, 1);
+  w.put(ix.ref_kmer_table.data(), ix.ref_kmer_table.size() * 8);
+  w.u64(ix.seq_starts.size());
+  for (size_t i = 0; i < ix.seq_starts.size(); i++) {
+    w.u64(ix.seq_starts[i]);
+    w.u64(ix.headers[i].size());
+    w.put(ix.headers[i].data(), ix.headers[i].size());
+  }
+  if (fflush(f) != 0) throw std::runtime_error("write failed: " + path);
+}
+
+// src/fm_index_file.rs:132-287, src/kmer_lookup_table.rs:55-77, src/sequence_index.rs:154-183
+void load_awry(HostIndex& ix, const std::string& path) {
+  FILE* f = fopen(path.c_str(), "rb");
+  if (!f) throw std::runtime_error("cannot open: " + path);
+  FileCloser fc{f};
+  Reader r{f};
+  char magic[11];
+  r.get(magic, 11);
+  if (memcmp(magic, MAGIC, 11) != 0) throw std::invalid_argument("not an AWRY index file (bad label)");
+  ix.version = r.u64();
+  ix.sa_ratio = r.u64();
+  ix.bwt_len = r.u64();
+  uint64_t alpha = r.u64();
+  if (alpha > 1) throw std::invalid_argument("invalid alphabet id in file");
+  if (ix.sa_ratio == 0 || ix.bwt_len == 0) throw std::invalid_argument("corrupt header");
+  ix.alphabet = (int)alpha;
+  if (ix.alphabet == AMINO && ix.bwt_len >= (1ull << 32)) throw std::invalid_argument("amino bwt_len >= 2^32 unsupported");
+  const int A = ix.alphabet, P = num_planes(A), BW = block_words(A), card = cardinality(A);
+  const int RW = 4 * P + (A == NUCLEOTIDE ? 8 : 24);
+  ix.nblocks = (ix.bwt_len + 255) / 256;
+  ix.sa_bits = csa_bits_per_element(ix.bwt_len);
+  ix.blocks.assign(ix.nblocks * BW, 0);
+  ix.sentinel_row = UINT64_MAX;
+  std::vector<uint64_t> buf((size_t)RW * 4096);
+  for (uint64_t b0 = 0; b0 < ix.nblocks; b0 += 4096) {
+    uint64_t nb = std::min<uint64_t>(4096, ix.nblocks - b0);
+    r.get(buf.data(), nb * RW * 8);
+    for (uint64_t j = 0; j < nb; j++) {
+      const uint64_t* in = buf.data() + j * RW;
+      block_from_reference(ix, b0 + j, in);
+      // locate the sentinel row: nt code 0b100; amino code 0b00000 on a row < bwt_len
+      for (int l = 0; l < 4; l++) {
+        uint64_t m;
+        if (A == NUCLEOTIDE) m = in[8 + l] & ~in[4 + l] & ~in[l];
+        else {
+          m = ~(in[l] | in[4 + l] | in[8 + l] | in[12 + l] | in[16 + l]);
+          uint64_t row0 = (b0 + j) * 256 + 64 * l;
+          if (row0 >= ix.bwt_len) m = 0;
+          else if (ix.bwt_len - row0 < 64) m &= (1ull << (ix.bwt_len - row0)) - 1;
+        }
+        if (m) ix.sentinel_row = (b0 + j) * 256 + 64 * l + (uint64_t)__builtin_ctzll(m);
+      }
+    }
+  }
+  if (ix.sentinel_row == UINT64_MAX) throw std::invalid_argument("no sentinel row in BWT");
+  ix.prefix_sums.resize(card + 1);
+  r.get(ix.prefix_sums.data(), (card + 1) * 8);
+  ix.sa_words.resize(csa_word_len(ix.bwt_len, ix.sa_ratio));
+  r.get(ix.sa_words.data(), ix.sa_words.size() * 8);
+  r.get(&ix.kmer_len, 1);
+  ix.ref_kmer_table.resize(2 * ref_kmer_table_entries(A, ix.kmer_len));
+  r.get(ix.ref_kmer_table.data(), ix.ref_kmer_table.size() * 8);
+  uint64_t ns = r.u64();
+  if (ns > (1ull << 40)) throw std::invalid_argument("corrupt sequence index");
+  ix.seq_starts.resize(ns);
+  ix.headers.resize(ns);
+  for (uint64_t i = 0; i < ns; i++) {
+    ix.seq_starts[i] = r.u64();
+    uint64_t hl = r.u64();
+    if (hl > (1ull << 32)) throw std::invalid_argument("corrupt header length");
+    ix.headers[i].resize(hl);
+    r.get(ix.headers[i].data(), hl);
+  }
+}
+
+}  // namespace awry

@@ -1,0 +1,484 @@
+// kernels.hip.h -- gfx950 (CDNA4, wave64) kernels of the FM-index hot path.
+//
+//   rank / Occ        /root/reference src/bwt.rs:114-135,230-271 + src/simd_instructions.rs:96-121
+//   step              src/fm_index.rs:559-582 (update_range_with_symbol)
+//   backward search   src/fm_index.rs:402-438 + src/kmer_lookup_table.rs:90-110
+//   backtrace/locate  src/fm_index.rs:516-544,585-593 + src/compressed_suffix_array.rs:76-111
+//   localisation      src/sequence_index.rs:108-141 (intended semantics)
+//
+// Integer/bit path only (no MFMA): every kernel is bound by random 128-B line fetches from HBM.
+// Two families:
+//   * "scalar" kernels: one query (or one hit) per lane, any alphabet, any symbol, any length;
+//   * "quad" kernels: the hot count path for packed nucleotide k-mers.  A wavefront holds 16
+//     independent queries, one per QUAD of lanes; a quad fetches a 128-B block as 2 x
+//     global_load_dwordx4 per lane (4 lanes x 16 B = one 64-B half line per instruction), ranks its
+//     64-symbol slice with __popcll and sums partials with two quad_perm DPP adds -- no LDS round trip.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "alphabet.h"
+#include "layout.h"
+
+namespace awry {
+
+// ------------------------------------------------------------------------------------------------
+// scalar helpers (one lane does a whole rank)
+// ------------------------------------------------------------------------------------------------
+
+// inclusive mask of bits 0..=t of a 64-symbol slice; t < 0 -> none, t >= 63 -> all
+__device__ __forceinline__ uint64_t slice_mask(int t) {
+  uint64_t m = ~0ull >> (63 - (t > 63 ? 63 : (t < 0 ? 0 : t)));
+  return t < 0 ? 0ull : m;
+}
+
+template <int A>
+__device__ __forceinline__ uint64_t slice_pred(const uint64_t* blk, int l, uint32_t code) {
+  uint64_t pr = ~0ull;
+#pragma unroll
+  for (int b = 0; b < (A == NUCLEOTIDE ? 3 : 5); b++) {
+    uint64_t x = ((code >> b) & 1u) ? 0ull : ~0ull;
+    pr &= blk[plane_word(A, b, l)] ^ x;
+  }
+  return pr;
+}
+
+// milestone of symbol index `idx` at the start of block `b` (exclusive prefix count, src/fm_index.rs:212-217)
+template <int A>
+__device__ __forceinline__ uint64_t milestone(const DevIndex& ix, const uint64_t* blk, uint64_t b, int idx) {
+  if (A == NUCLEOTIDE) {
+    int letter = nt_letter_of_index(idx);
+    if (letter >= 0) return blk[nt_ms_word(letter)];
+    // N is derived: rows before the block that are neither A,C,G,T nor the single '$'
+    uint64_t sum = blk[nt_ms_word(0)] + blk[nt_ms_word(1)] + blk[nt_ms_word(2)] + blk[nt_ms_word(3)];
+    return 256ull * b - sum - (ix.sentinel_row < 256ull * b ? 1ull : 0ull);
+  }
+  int t = idx - 1;
+  return (blk[aa_ms_word(t)] >> (32 * aa_ms_half(t))) & 0xffffffffull;
+}
+
+// Occ(idx, row) inclusive of `row`: src/bwt.rs:338-357
+template <int A>
+__device__ __forceinline__ uint64_t rank_scalar(const DevIndex& ix, uint64_t row, int idx) {
+  const uint64_t b = row >> 8;
+  const int p = (int)(row & 255);
+  const uint64_t* blk = ix.blocks + b * (A == NUCLEOTIDE ? NT_BLOCK_WORDS : AA_BLOCK_WORDS);
+  const uint32_t code = A == NUCLEOTIDE ? nt_code_of_index(idx) : aa_code_of_index(idx);
+  uint32_t cnt = 0;
+#pragma unroll
+  for (int l = 0; l < 4; l++) cnt += (uint32_t)__popcll(slice_pred<A>(blk, l, code) & slice_mask(p - 64 * l));
+  return milestone<A>(ix, blk, b, idx) + cnt;
+}
+
+// symbol index stored at BWT row `row`: src/bwt.rs:307-325
+template <int A>
+__device__ __forceinline__ int symbol_at(const DevIndex& ix, uint64_t row) {
+  const uint64_t* blk = ix.blocks + (row >> 8) * (A == NUCLEOTIDE ? NT_BLOCK_WORDS : AA_BLOCK_WORDS);
+  const int l = (int)((row >> 6) & 3), bit = (int)(row & 63);
+  uint32_t code = 0;
+#pragma unroll
+  for (int b = 0; b < (A == NUCLEOTIDE ? 3 : 5); b++) code |= (uint32_t)((blk[plane_word(A, b, l)] >> bit) & 1ull) << b;
+  return A == NUCLEOTIDE ? nt_index_of_code(code) : aa_index_of_code(code);
+}
+
+// src/fm_index.rs:559-582
+template <int A>
+__device__ __forceinline__ void step_scalar(const DevIndex& ix, uint64_t& sp, uint64_t& ep, int idx) {
+  const uint64_t c = ix.prefix_sums[idx];
+  const uint64_t s2 = c + rank_scalar<A>(ix, sp - 1, idx);
+  ep = c + rank_scalar<A>(ix, ep, idx) - 1;
+  sp = s2;
+}
+
+// src/fm_index.rs:585-593
+template <int A>
+__device__ __forceinline__ uint64_t backstep_scalar(const DevIndex& ix, uint64_t row) {
+  int idx = symbol_at<A>(ix, row);
+  if (idx == 0) return 0;
+  return ix.prefix_sums[idx] + rank_scalar<A>(ix, row, idx) - 1;
+}
+
+// src/compressed_suffix_array.rs:76-106
+__device__ __forceinline__ uint64_t sa_sample(const DevIndex& ix, uint64_t sample) {
+  const uint64_t bits = ix.sa_bits;
+  if (bits == 0) return 0;
+  const uint64_t off = sample * bits, w = off >> 6, s = off & 63;
+  uint64_t v = ix.sa_words[w] >> s;
+  if (s + bits > 64) v |= ix.sa_words[w + 1] << (64 - s);
+  return bits >= 64 ? v : (v & ((1ull << bits) - 1));
+}
+
+// ------------------------------------------------------------------------------------------------
+// generic count: one ASCII query per lane (any alphabet / symbol / length)
+// ------------------------------------------------------------------------------------------------
+
+enum : uint8_t { Q_OK = 0, Q_EMPTY = 1, Q_SENTINEL = 2, Q_NON_ASCII = 3 };
+
+// status[q] != 0 marks inputs the reference leaves undefined: empty query, '$'/'#',
+// bytes >= 0x80.  ranges (optional) receives the final (start, end) row interval.
+template <int A>
+__global__ __launch_bounds__(256) void count_scalar_kernel(DevIndex ix, const uint8_t* __restrict__ ascii,
+                                                           const uint64_t* __restrict__ off, uint64_t n,
+                                                           uint64_t* __restrict__ counts, uint64_t* __restrict__ ranges,
+                                                           uint8_t* __restrict__ status) {
+  __shared__ uint8_t lut[256];
+  lut[threadIdx.x] = (uint8_t)(threadIdx.x >= 128 ? 0xFF : index_of_ascii(A, (uint8_t)threadIdx.x));
+  __syncthreads();
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += stride) {
+    const uint64_t b = off[q], e = off[q + 1];
+    uint8_t st = e > b ? Q_OK : Q_EMPTY;
+    for (uint64_t i = b; i < e; i++) {
+      uint8_t s = lut[ascii[i]];
+      if (s == 0xFF) st = Q_NON_ASCII;
+      else if (s == 0 && st == Q_OK) st = Q_SENTINEL;
+    }
+    uint64_t sp = 1, ep = 0;
+    if (st == Q_OK) {
+      uint64_t i = e - 1;
+      int idx = lut[ascii[i]];
+      sp = ix.prefix_sums[idx];          // SearchRange::new, src/search.rs:43-48
+      ep = ix.prefix_sums[idx + 1] - 1;
+      while (i > b && sp <= ep) {        // emptiness is sticky, so stopping early never changes the count
+        i--;
+        step_scalar<A>(ix, sp, ep, lut[ascii[i]]);
+      }
+    }
+    counts[q] = sp > ep ? 0 : ep - sp + 1;  // src/search.rs:66-71
+    if (ranges) { ranges[2 * q] = sp; ranges[2 * q + 1] = ep; }
+    if (status) status[q] = st;
+  }
+}
+
+// one step / one backstep / one initial range for the scalar conveniences of the C ABI
+template <int A>
+__global__ void scalar_ops_kernel(DevIndex ix, int op, uint64_t a, uint64_t b, int idx, uint64_t* out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  if (op == 0) {  // update_range_with_symbol
+    uint64_t sp = a, ep = b;
+    step_scalar<A>(ix, sp, ep, idx);
+    out[0] = sp; out[1] = ep;
+  } else if (op == 1) {  // backstep
+    out[0] = backstep_scalar<A>(ix, a);
+  } else if (op == 2) {  // global_occurrence
+    out[0] = rank_scalar<A>(ix, a, idx);
+  } else {  // symbol_at
+    out[0] = (uint64_t)symbol_at<A>(ix, a);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// the reference's k-mer table content, for byte-identical .awry files (src/kmer_lookup_table.rs:121-167):
+// slot = sum_j s_j * sigma^j with s_0 = LAST symbol, digits restricted to 1..sigma-1; steps are applied
+// without any emptiness check; every other slot stays SearchRange::zero() = {1, 0}.
+// ------------------------------------------------------------------------------------------------
+template <int A>
+__global__ __launch_bounds__(256) void ref_kmer_table_kernel(DevIndex ix, int kmer_len, uint64_t nslots,
+                                                             uint64_t* __restrict__ table) {
+  const uint64_t sigma = A == NUCLEOTIDE ? 4 : 20;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t slot = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; slot < nslots; slot += stride) {
+    uint64_t sp = 1, ep = 0, rem = slot;
+    bool populated = kmer_len > 0;
+    for (int j = 0; j < kmer_len; j++) {
+      if (rem % sigma == 0) populated = false;
+      rem /= sigma;
+    }
+    if (populated) {
+      rem = slot;
+      int idx = (int)(rem % sigma);
+      rem /= sigma;
+      sp = ix.prefix_sums[idx];
+      ep = ix.prefix_sums[idx + 1] - 1;
+      for (int j = 1; j < kmer_len; j++) {
+        idx = (int)(rem % sigma);
+        rem /= sigma;
+        step_scalar<A>(ix, sp, ep, idx);
+      }
+    }
+    table[2 * slot] = sp;
+    table[2 * slot + 1] = ep;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// locate: one hit per lane.  hit h belongs to the query q with hit_off[q] <= h < hit_off[q+1]; its BWT
+// row is ranges[2q] + (h - hit_off[q]) -- ascending row order inside a query, src/fm_index.rs:521.
+// ------------------------------------------------------------------------------------------------
+template <int A>
+__global__ __launch_bounds__(256) void locate_scalar_kernel(DevIndex ix, const uint64_t* __restrict__ ranges,
+                                                            const uint64_t* __restrict__ hit_off, uint64_t n,
+                                                            uint64_t total, uint64_t* __restrict__ gpos,
+                                                            uint64_t* __restrict__ pos /* (seq_idx, local) pairs */) {
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t h = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; h < total; h += stride) {
+    uint64_t lo = 0, hi = n;  // largest q with hit_off[q] <= h
+    while (hi - lo > 1) {
+      uint64_t mid = (lo + hi) >> 1;
+      if (hit_off[mid] <= h) lo = mid; else hi = mid;
+    }
+    uint64_t row = ranges[2 * lo] + (h - hit_off[lo]);
+    uint64_t steps = 0;
+    while (row % ix.sa_ratio != 0) {  // position_is_sampled, src/compressed_suffix_array.rs:109-111
+      row = backstep_scalar<A>(ix, row);
+      steps++;
+    }
+    const uint64_t g = (sa_sample(ix, row / ix.sa_ratio) + steps) % ix.bwt_len;  // src/fm_index.rs:534
+    gpos[h] = g;
+    if (pos) {
+      uint64_t a = 0, z = ix.nseq;  // largest i with seq_starts[i] <= g
+      while (z - a > 1) {
+        uint64_t mid = (a + z) >> 1;
+        if (ix.seq_starts[mid] <= g) a = mid; else z = mid;
+      }
+      pos[2 * h] = a;
+      pos[2 * h + 1] = g - (ix.nseq ? ix.seq_starts[a] : 0);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// exclusive scan of u64 counts (locate's CSR offsets): per-tile sums, scan of tile sums, fix-up
+// ------------------------------------------------------------------------------------------------
+constexpr int SCAN_TILE = 2048;  // elements per 256-thread block
+
+__device__ __forceinline__ uint64_t wave_incl_scan(uint64_t v) {
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    uint64_t o = __shfl_up(v, d, 64);
+    if (lane >= d) v += o;
+  }
+  return v;
+}
+
+// block-wide exclusive scan of one value per thread (256 threads); returns exclusive prefix, total in *tot
+__device__ __forceinline__ uint64_t block_excl_scan(uint64_t v, uint64_t* tot) {
+  __shared__ uint64_t wsum[4];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  uint64_t inc = wave_incl_scan(v);
+  if (lane == 63) wsum[wv] = inc;
+  __syncthreads();
+  uint64_t base = 0, t = 0;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    if (i < wv) base += wsum[i];
+    t += wsum[i];
+  }
+  __syncthreads();
+  *tot = t;
+  return base + inc - v;
+}
+
+__global__ __launch_bounds__(256) void scan_tile_sums_kernel(const uint64_t* __restrict__ in, uint64_t n,
+                                                             uint64_t* __restrict__ tile_sums) {
+  const uint64_t base = (uint64_t)blockIdx.x * SCAN_TILE;
+  uint64_t s = 0;
+  for (int j = 0; j < SCAN_TILE / 256; j++) {
+    uint64_t i = base + (uint64_t)j * 256 + threadIdx.x;
+    if (i < n) s += in[i];
+  }
+  uint64_t tot;
+  block_excl_scan(s, &tot);
+  if (threadIdx.x == 0) tile_sums[blockIdx.x] = tot;
+}
+
+// single block: exclusive scan of tile sums in place; writes the grand total to *total
+__global__ __launch_bounds__(256) void scan_tile_offsets_kernel(uint64_t* __restrict__ tile_sums, uint64_t ntiles,
+                                                                uint64_t* __restrict__ total) {
+  uint64_t carry = 0;
+  for (uint64_t b = 0; b < ntiles; b += 256) {
+    uint64_t i = b + threadIdx.x;
+    uint64_t v = i < ntiles ? tile_sums[i] : 0, tot;
+    uint64_t ex = block_excl_scan(v, &tot);
+    if (i < ntiles) tile_sums[i] = carry + ex;
+    carry += tot;
+  }
+  if (threadIdx.x == 0) *total = carry;
+}
+
+// out has n + 1 entries; out[n] = grand total
+__global__ __launch_bounds__(256) void scan_apply_kernel(const uint64_t* __restrict__ in, uint64_t n,
+                                                         const uint64_t* __restrict__ tile_offs,
+                                                         uint64_t* __restrict__ out) {
+  const uint64_t base = (uint64_t)blockIdx.x * SCAN_TILE;
+  uint64_t carry = tile_offs[blockIdx.x];
+  for (int j = 0; j < SCAN_TILE / 256; j++) {
+    uint64_t i = base + (uint64_t)j * 256 + threadIdx.x;
+    uint64_t v = i < n ? in[i] : 0, tot;
+    uint64_t ex = block_excl_scan(v, &tot);
+    if (i < n) out[i] = carry + ex;
+    if (i == n - 1) out[n] = carry + ex + v;
+    carry += tot;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// quad-cooperative nucleotide path (bwt_len < 2^32): packed 2-bit k-mers, seed table, persistent quads
+// ------------------------------------------------------------------------------------------------
+
+// sum over the 4 lanes of a quad; every lane receives the total (quad_perm DPP, no LDS)
+__device__ __forceinline__ uint32_t quad_sum(uint32_t v) {
+  v += (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true);  // quad_perm [1,0,3,2]
+  v += (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xF, 0xF, true);  // quad_perm [2,3,0,1]
+  return v;
+}
+
+// 2-bit letter (A0 C1 G2 T3) -> per-plane XOR masks of its 3-bit code (A110 C101 G011 T001)
+struct NtXor { uint64_t x0, x1, x2; };
+__device__ __forceinline__ NtXor nt_xor_of_letter(uint32_t c) {
+  const uint32_t code = (0x1356u >> (4 * c)) & 7u;  // nibbles: A=6, C=5, G=3, T=1
+  NtXor r;
+  r.x0 = (code & 1u) ? 0ull : ~0ull;
+  r.x1 = (code & 2u) ? 0ull : ~0ull;
+  r.x2 = (code & 4u) ? 0ull : ~0ull;
+  return r;
+}
+
+struct QuadBlock { ulonglong2 lo, hi; };  // lane l: lo = {plane0[l], plane1[l]}, hi = {plane2[l], milestone[l]}
+
+__device__ __forceinline__ QuadBlock quad_load(const uint64_t* __restrict__ blocks, uint32_t b, int l) {
+  const ulonglong2* p = reinterpret_cast<const ulonglong2*>(blocks + (uint64_t)b * NT_BLOCK_WORDS);
+  QuadBlock q;
+  q.lo = p[l];      // bytes [16 l, 16 l + 16) of the first half line
+  q.hi = p[4 + l];  // bytes [64 + 16 l, ...) of the second half line
+  return q;
+}
+
+// this lane's share of C-free rank(row, letter c): popcount of its slice + the milestone if it owns it
+__device__ __forceinline__ uint32_t quad_rank_part(const QuadBlock& d, const NtXor& x, uint32_t row, uint32_t c, int l) {
+  const uint64_t pred = (d.lo.x ^ x.x0) & (d.lo.y ^ x.x1) & (d.hi.x ^ x.x2);
+  const uint32_t cnt = (uint32_t)__popcll(pred & slice_mask((int)(row & 255u) - 64 * l));
+  return cnt + ((uint32_t)l == c ? (uint32_t)d.hi.y : 0u);
+}
+
+// one backward-search step for the quad's query: [sp, ep] -> [sp', ep'] with letter c (src/fm_index.rs:559-582)
+__device__ __forceinline__ void quad_step(const uint64_t* __restrict__ blocks, uint32_t cl, uint32_t& sp, uint32_t& ep,
+                                          uint32_t c, int l) {
+  const uint32_t r0 = sp - 1, r1 = ep;
+  const uint32_t b0 = r0 >> 8, b1 = r1 >> 8;
+  QuadBlock d0 = quad_load(blocks, b0, l);
+  QuadBlock d1 = d0;
+  if (b1 != b0) d1 = quad_load(blocks, b1, l);  // most steps rank both rows in one block
+  const NtXor x = nt_xor_of_letter(c);
+  const uint32_t v0 = quad_sum(quad_rank_part(d0, x, r0, c, l));
+  const uint32_t v1 = quad_sum(quad_rank_part(d1, x, r1, c, l));
+  sp = cl + v0;
+  ep = cl + v1 - 1;
+}
+
+// Count fixed-length packed k-mers.  Query word: letter j (0 = leftmost) in bits [2j, 2j+2).
+// Every quad walks its own strided list of queries (q = quad id, += number of quads) as a small state
+// machine: one random HBM access group (a seed probe or the block(s) of one step) per loop iteration, so
+// quads that finish early immediately start their next query instead of idling behind slower ones.
+// TALLY adds the work census the roofline figure is computed from: tally[0] += seed probes,
+// tally[1] += executed steps, tally[2] += distinct BWT blocks ranked (1 or 2 per step), SURVEY.md 8(d).
+template <bool USE_SEED, bool TALLY>
+__global__ __launch_bounds__(256) void count_nt2_quad_kernel(DevIndex ix, const uint64_t* __restrict__ queries, uint64_t n, int L,
+                                                             uint64_t* __restrict__ counts, unsigned long long* __restrict__ tally) {
+  const int l = threadIdx.x & 3;
+  const uint64_t nquads = ((uint64_t)gridDim.x * blockDim.x) >> 2;
+  uint64_t q = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 2;
+  const uint64_t* __restrict__ blocks = ix.blocks;
+  const SeedEntry* __restrict__ seed = ix.seed;
+  const int k = USE_SEED ? ix.seed_k : 1;
+  const uint32_t cA = (uint32_t)ix.prefix_sums[1], cC = (uint32_t)ix.prefix_sums[2], cG = (uint32_t)ix.prefix_sums[3],
+                 cN = (uint32_t)ix.prefix_sums[4], cT = (uint32_t)ix.prefix_sums[5], cEnd = (uint32_t)ix.prefix_sums[6];
+
+  bool have = q < n;
+  uint64_t w = have ? queries[q] : 0;
+  bool fresh = true;  // next access is the seed probe / initial range of query q
+  uint32_t sp = 1, ep = 0;
+  int i = 0;  // symbols still to consume (the next one is letter i-1)
+  uint32_t t_probe = 0, t_step = 0, t_blk = 0;
+
+  while (__any(have)) {
+    if (have) {
+      if (fresh) {
+        if (USE_SEED) {
+          const uint32_t sidx = (uint32_t)((w >> (2 * (L - k))) & ((1ull << (2 * k)) - 1));
+          const SeedEntry e = seed[sidx];
+          sp = e.cnt ? e.sp : 1u;
+          ep = e.cnt ? e.sp + e.cnt - 1u : 0u;
+          if (TALLY) t_probe++;
+        } else {
+          const uint32_t c = (uint32_t)(w >> (2 * (L - 1))) & 3u;  // SearchRange::new(last symbol)
+          sp = c == 0 ? cA : (c == 1 ? cC : (c == 2 ? cG : cT));
+          ep = (c == 0 ? cC : (c == 1 ? cG : (c == 2 ? cN : cEnd))) - 1;
+        }
+        i = L - k;
+        fresh = false;
+      } else {
+        i--;
+        const uint32_t c = (uint32_t)(w >> (2 * i)) & 3u;
+        const uint32_t cl = c == 0 ? cA : (c == 1 ? cC : (c == 2 ? cG : cT));
+        if (TALLY) { t_step++; t_blk += ((sp - 1) >> 8) == (ep >> 8) ? 1u : 2u; }
+        quad_step(blocks, cl, sp, ep, c, l);
+      }
+      if (sp > ep || i == 0) {
+        if (l == 0) counts[q] = sp > ep ? 0ull : (uint64_t)(ep - sp) + 1ull;
+        q += nquads;
+        have = q < n;
+        if (have) w = queries[q];
+        fresh = true;
+      }
+    }
+  }
+  if (TALLY && l == 0) {
+    atomicAdd(&tally[0], (unsigned long long)t_probe);
+    atomicAdd(&tally[1], (unsigned long long)t_step);
+    atomicAdd(&tally[2], (unsigned long long)t_blk);
+  }
+}
+
+// Seed table, level by level: entry o of level j+1 (window letters w_0..w_j, index = sum w_t 4^t with the
+// LAST query symbol most significant) is one step of its parent o >> 2 with letter o & 3.
+__global__ __launch_bounds__(256) void seed_level1_kernel(DevIndex ix, SeedEntry* __restrict__ out) {
+  if (blockIdx.x == 0 && threadIdx.x < 4) {
+    const int idx = nt_index_of_letter((int)threadIdx.x);
+    const uint64_t s = ix.prefix_sums[idx], e = ix.prefix_sums[idx + 1];
+    out[threadIdx.x] = SeedEntry{(uint32_t)s, (uint32_t)(e - s)};
+  }
+}
+
+__global__ __launch_bounds__(256) void seed_extend_kernel(DevIndex ix, const SeedEntry* __restrict__ parent,
+                                                          SeedEntry* __restrict__ child, uint64_t nchild) {
+  const int l = threadIdx.x & 3;
+  const uint64_t nquads = ((uint64_t)gridDim.x * blockDim.x) >> 2;
+  const uint32_t cA = (uint32_t)ix.prefix_sums[1], cC = (uint32_t)ix.prefix_sums[2], cG = (uint32_t)ix.prefix_sums[3],
+                 cT = (uint32_t)ix.prefix_sums[5];
+  for (uint64_t o = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 2; o < nchild; o += nquads) {
+    const SeedEntry p = parent[o >> 2];
+    SeedEntry r{p.sp, 0};
+    if (p.cnt) {
+      const uint32_t c = (uint32_t)(o & 3);
+      const uint32_t cl = c == 0 ? cA : (c == 1 ? cC : (c == 2 ? cG : cT));
+      uint32_t sp = p.sp, ep = p.sp + p.cnt - 1;
+      quad_step(ix.blocks, cl, sp, ep, c, l);
+      r.sp = sp;
+      r.cnt = sp > ep ? 0u : ep - sp + 1u;
+    }
+    if (l == 0) child[o] = r;
+  }
+}
+
+// ASCII fixed-length k-mers -> packed words; *bad counts queries with a byte outside ACGTacgt (U counts too:
+// the caller then takes the generic path, which applies the full alphabet map)
+__global__ __launch_bounds__(256) void pack_nt2_kernel(const uint8_t* __restrict__ ascii, uint64_t n, int L,
+                                                       uint64_t* __restrict__ words, unsigned long long* __restrict__ bad) {
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += stride) {
+    const uint8_t* p = ascii + q * (uint64_t)L;
+    uint64_t w = 0;
+    bool ok = true;
+    for (int j = 0; j < L; j++) {
+      uint8_t a = p[j] & 0xDF;  // upper-case
+      uint32_t c = a == 'A' ? 0u : (a == 'C' ? 1u : (a == 'G' ? 2u : (a == 'T' ? 3u : 4u)));
+      ok = ok && c < 4u && p[j] < 0x80;
+      w |= (uint64_t)(c & 3u) << (2 * j);
+    }
+    words[q] = w;
+    if (!ok) atomicAdd(bad, 1ull);
+  }
+}
+
+}  // namespace awry

@@ -1,0 +1,80 @@
+// layout.h -- HBM-resident index layout shared by host packers and gfx950 kernels.
+//
+// The reference stores a 256-symbol BWT block as P bit-planes (Vec256 = 4 x u64) followed by 8 / 24
+// u64 milestones: 160 B (nucleotide) / 352 B (amino), 32-B aligned (/root/reference src/bwt.rs:12-30,
+// 139-140).  Neither is a multiple of the 128-B L2 line, so one rank touches 2-4 lines.  The device
+// layout is re-derived for CDNA4: a block is exactly one (nt) or two (aa) 128-B lines and is laid out
+// so that the four lanes of a wavefront QUAD each own one 64-symbol slice (= one u64 word of every
+// plane, the w-th word of the reference's Vec256) plus a share of the milestones.  A quad fetches a
+// block with `global_load_dwordx4` instructions whose four lanes cover 64 contiguous bytes, ranks its
+// slice with 64-bit popcounts, and sums the partials with two quad_perm DPP adds.
+//
+// Nucleotide block: 16 u64 words (128 B), quad lane l in 0..3:
+//     word 2l   = plane0 word l      word 2l+1 = plane1 word l          (first 64-B half line)
+//     word 8+2l = plane2 word l      word 9+2l = milestone of letter l  (second half), letters A,C,G,T
+//   The '$' and N milestones of the reference (src/fm_index.rs:212-217) are derivable and not stored:
+//     '$': exactly one sentinel row s  ->  [s < 256 b]
+//     N  : 256 b - (A + C + G + T) - [s < 256 b]
+// Amino block: 32 u64 words (256 B), quad lane l:
+//     word 2l = plane0[l]  2l+1 = plane1[l] | 8+2l = plane2[l]  9+2l = plane3[l]
+//     16+2l = plane4[l]    17+2l = ms32 pair 0  | 24+2l = ms32 pair 1  25+2l = ms32 pair 2
+//   u32 milestone slot t = symbol_index - 1 (t in 0..20, i.e. A..W, X, Y) lives in lane t/6, pair
+//   (t%6)/2, half (t%6)&1.  u32 milestones require bwt_len < 2^32 (Swiss-Prot: 9e7).
+//
+// Symbol codes inside the planes are the reference's (src/alphabet.rs:280-325), so converting to and
+// from the .awry file layout (src/fm_index_file.rs:58-67) is a pure word permutation.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIP__)  // compiled as HIP (kernels + runtime TU); plain C++ TUs get ordinary inline functions
+#define AWRY_HD __host__ __device__ inline __attribute__((always_inline))
+#else
+#define AWRY_HD inline
+#endif
+
+namespace awry {
+
+enum : int { NUCLEOTIDE = 0, AMINO = 1 };
+
+constexpr int NT_BLOCK_WORDS = 16;  // 128 B
+constexpr int AA_BLOCK_WORDS = 32;  // 256 B
+constexpr int SYMBOLS_PER_BLOCK = 256;  // src/bwt.rs:285
+
+AWRY_HD int block_words(int alphabet) { return alphabet == NUCLEOTIDE ? NT_BLOCK_WORDS : AA_BLOCK_WORDS; }
+AWRY_HD int num_planes(int alphabet) { return alphabet == NUCLEOTIDE ? 3 : 5; }
+AWRY_HD int cardinality(int alphabet) { return alphabet == NUCLEOTIDE ? 6 : 22; }  // src/alphabet.rs:87-92
+
+// word index of plane `b`, slice `l` inside a device block
+AWRY_HD int plane_word(int alphabet, int b, int l) {
+  if (alphabet == NUCLEOTIDE) return b < 2 ? 2 * l + b : 8 + 2 * l;
+  return b < 2 ? 2 * l + b : (b < 4 ? 8 + 2 * l + (b - 2) : 16 + 2 * l);
+}
+// nucleotide: word of the u64 milestone of letter l (0..3 = A,C,G,T)
+AWRY_HD int nt_ms_word(int l) { return 9 + 2 * l; }
+// amino: (word, half) of u32 milestone slot t (= symbol index - 1)
+AWRY_HD int aa_ms_word(int t) {
+  int l = t / 6, j = t % 6;
+  return j < 2 ? 17 + 2 * l : (j < 4 ? 24 + 2 * l : 25 + 2 * l);
+}
+AWRY_HD int aa_ms_half(int t) { return (t % 6) & 1; }
+
+// nucleotide symbol index (src/alphabet.rs:230-235: $0 A1 C2 G3 N4 T5) -> milestone letter 0..3, or -1
+AWRY_HD int nt_letter_of_index(int idx) { return idx == 5 ? 3 : (idx >= 1 && idx <= 3 ? idx - 1 : -1); }
+AWRY_HD int nt_index_of_letter(int l) { return l == 3 ? 5 : l + 1; }
+
+// seed-table entry: the search range of a k-mer as (start row, row count); count 0 = absent
+struct SeedEntry { uint32_t sp, cnt; };
+
+// Everything a kernel needs, passed by value (fits the kernarg segment).
+struct DevIndex {
+  const uint64_t* blocks;     // nblocks * block_words(alphabet), 128-B aligned
+  const uint64_t* sa_words;   // bit-packed sampled SA, src/compressed_suffix_array.rs:51-64
+  const SeedEntry* seed;      // sigma^seed_k entries or nullptr
+  const uint64_t* seq_starts; // nseq record start offsets
+  uint64_t nblocks, bwt_len, sentinel_row, nseq;
+  uint64_t prefix_sums[24];   // C[i], src/fm_index.rs:233-240
+  uint32_t sa_bits, sa_ratio;
+  int32_t alphabet, seed_k;
+};
+
+}  // namespace awry

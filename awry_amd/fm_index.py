@@ -1,0 +1,367 @@
+"""Host-side mirror of the reference's public `FmIndex` surface (/root/reference src/fm_index.rs) over the
+C ABI of libawry_hip.so.  Same names, argument meaning and error behaviour: query functions raise where
+the reference panics (empty query, '$'/'#').  All searching happens in HIP kernels on the GPU(s) chosen
+with `set_devices`; nothing here computes a count or a location on the CPU."""
+import ctypes as C
+import os
+from dataclasses import dataclass
+from typing import Iterable, List, Optional, Sequence
+
+import numpy as np
+
+from . import _lib
+
+NUCLEOTIDE, AMINO = 0, 1
+
+
+class SymbolAlphabet:  # src/alphabet.rs:28-31
+    Nucleotide = NUCLEOTIDE
+    Amino = AMINO
+
+
+class AwryError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("awry error %d: %s" % (code, msg))
+        self.code = code
+
+
+ERR_IO, ERR_FORMAT, ERR_INVALID_QUERY, ERR_HIP, ERR_OOM, ERR_ARG, ERR_NO_DEVICE = -1, -2, -3, -4, -5, -6, -7
+
+
+@dataclass
+class FmBuildArgs:  # src/fm_index.rs:78-96
+    input_file_src: str
+    suffix_array_output_src: Optional[str] = None
+    suffix_array_compression_ratio: Optional[int] = None
+    lookup_table_kmer_len: Optional[int] = None
+    alphabet: int = NUCLEOTIDE
+    max_query_len: Optional[int] = None
+    remove_intermediate_suffix_array_file: bool = False
+
+
+@dataclass(frozen=True, order=True)
+class LocalizedSequencePosition:  # src/sequence_index.rs:31-78
+    sequence_idx: int
+    local_position: int
+
+
+@dataclass(frozen=True, order=True)
+class SearchRange:  # src/search.rs:25-81
+    start_ptr: int
+    end_ptr: int
+
+    @staticmethod
+    def zero():
+        return SearchRange(1, 0)
+
+    def is_empty(self):
+        return self.start_ptr > self.end_ptr
+
+    def len(self):
+        return 0 if self.is_empty() else self.end_ptr - self.start_ptr + 1
+
+    def range_iter(self):
+        return range(0) if self.is_empty() else range(self.start_ptr, self.end_ptr + 1)
+
+
+def _check(rc):
+    if rc != 0:
+        raise AwryError(rc, _lib.load_library().awry_last_error().decode(errors="replace"))
+
+
+def _as_bytes(q):
+    if isinstance(q, str):
+        return q.encode("latin-1")
+    if isinstance(q, np.ndarray):
+        return np.ascontiguousarray(q, dtype=np.uint8).tobytes()
+    return bytes(q)
+
+
+def pack_queries(queries: Iterable):
+    """iterable of str / bytes / uint8 arrays -> (uint8[total], uint64[n+1]) CSR"""
+    qs = [_as_bytes(q) for q in queries]
+    off = np.zeros(len(qs) + 1, dtype=np.uint64)
+    if qs:
+        off[1:] = np.cumsum([len(q) for q in qs], dtype=np.uint64)
+    buf = np.frombuffer(b"".join(qs), dtype=np.uint8).copy() if qs else np.zeros(0, np.uint8)
+    return buf, off
+
+
+_u64p = C.POINTER(C.c_uint64)
+
+
+class FmIndex:
+    def __init__(self, handle):
+        self._L = _lib.load_library()
+        self._h = C.c_void_p(handle)
+
+    # ------------------------------------------------------------------ construction / persistence
+    @classmethod
+    def new(cls, args: FmBuildArgs) -> "FmIndex":
+        """FmIndex::new, src/fm_index.rs:142-268"""
+        L = _lib.load_library()
+        a = _lib.BuildArgs(os.fsencode(args.input_file_src),
+                           os.fsencode(args.suffix_array_output_src) if args.suffix_array_output_src else None,
+                           args.suffix_array_compression_ratio or 0, args.lookup_table_kmer_len or 0, args.alphabet,
+                           args.max_query_len or 0, 1 if args.remove_intermediate_suffix_array_file else 0)
+        h = C.c_void_p()
+        _check(L.awry_build(C.byref(a), C.byref(h)))
+        return cls(h.value)
+
+    @classmethod
+    def from_text(cls, text, alphabet=NUCLEOTIDE, sa_ratio=8, kmer_len=0, seq_starts=(0,), headers=("seq0",)) -> "FmIndex":
+        """index an in-memory text that already follows the reference's text model (ends in '$')"""
+        L = _lib.load_library()
+        t = np.frombuffer(_as_bytes(text), dtype=np.uint8) if not isinstance(text, np.ndarray) else np.ascontiguousarray(text, np.uint8)
+        st = np.ascontiguousarray(list(seq_starts), dtype=np.uint64)
+        hd = (C.c_char_p * len(headers))(*[h.encode() for h in headers])
+        h = C.c_void_p()
+        _check(L.awry_build_from_text(t.ctypes.data, len(t), alphabet, sa_ratio, kmer_len, st.ctypes.data_as(_u64p), hd,
+                                      len(headers), C.byref(h)))
+        return cls(h.value)
+
+    @classmethod
+    def load(cls, path) -> "FmIndex":
+        """FmIndex::load, src/fm_index_file.rs:132"""
+        L = _lib.load_library()
+        h = C.c_void_p()
+        _check(L.awry_load(os.fsencode(path), C.byref(h)))
+        return cls(h.value)
+
+    def save(self, path):
+        """FmIndex::save, src/fm_index_file.rs:42"""
+        _check(self._L.awry_save(self._h, os.fsencode(path)))
+
+    def close(self):
+        if self._h:
+            self._L.awry_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ device placement
+    def set_devices(self, device_ids: Sequence[int] = (0,)) -> "FmIndex":
+        ids = (C.c_int * len(device_ids))(*device_ids)
+        _check(self._L.awry_set_devices(self._h, ids, len(device_ids)))
+        return self
+
+    def set_seed_kmer_len(self, k: int):
+        _check(self._L.awry_set_seed_kmer_len(self._h, k))
+
+    def seed_kmer_len(self) -> int:
+        return self._L.awry_seed_kmer_len(self._h)
+
+    def num_devices(self) -> int:
+        return self._L.awry_num_devices(self._h)
+
+    # ------------------------------------------------------------------ accessors (src/fm_index.rs:302-399)
+    def alphabet(self) -> int:
+        return self._L.awry_alphabet(self._h)
+
+    def bwt_len(self) -> int:
+        return int(self._L.awry_bwt_len(self._h))
+
+    def version_number(self) -> int:
+        return int(self._L.awry_version(self._h))
+
+    def suffix_array_compression_ratio(self) -> int:
+        return int(self._L.awry_sa_ratio(self._h))
+
+    def lookup_table_kmer_len(self) -> int:
+        return int(self._L.awry_kmer_len(self._h))
+
+    def sentinel_row(self) -> int:
+        return int(self._L.awry_sentinel_row(self._h))
+
+    def _arr(self, fn):
+        n = C.c_uint64()
+        p = getattr(self._L, fn)(self._h, C.byref(n))
+        return np.ctypeslib.as_array(p, shape=(int(n.value),)).copy() if n.value else np.zeros(0, np.uint64)
+
+    def prefix_sums(self) -> np.ndarray:
+        return self._arr("awry_prefix_sums")
+
+    def device_block_words(self) -> np.ndarray:
+        return self._arr("awry_block_words")
+
+    def sa_words(self) -> np.ndarray:
+        return self._arr("awry_sa_words")
+
+    def reference_block_words(self) -> np.ndarray:
+        """all BWT blocks converted to the reference layout (planes then milestones, src/bwt.rs:12-25)"""
+        rw = 20 if self.alphabet() == NUCLEOTIDE else 44
+        nb = (self.bwt_len() + 255) // 256
+        out = np.zeros(nb * rw, dtype=np.uint64)
+        for b in range(nb):
+            _check(self._L.awry_block_reference_layout(self._h, b, out[b * rw:].ctypes.data_as(_u64p), rw))
+        return out
+
+    def sequences(self):
+        n = int(self._L.awry_num_sequences(self._h))
+        return [(int(self._L.awry_sequence_start(self._h, i)), self._L.awry_sequence_header(self._h, i).decode()) for i in range(n)]
+
+    # ------------------------------------------------------------------ scalar queries
+    def count_string(self, query) -> int:
+        """src/fm_index.rs:499-501"""
+        q = _as_bytes(query)
+        c = C.c_uint64()
+        _check(self._L.awry_count(self._h, q, len(q), C.byref(c)))
+        return int(c.value)
+
+    def search_range(self, query) -> SearchRange:
+        """get_search_range_for_string, src/fm_index.rs:402-438"""
+        q = _as_bytes(query)
+        r = _lib.Range()
+        _check(self._L.awry_search_range(self._h, q, len(q), C.byref(r)))
+        return SearchRange(int(r.start_ptr), int(r.end_ptr))
+
+    def locate_string(self, query) -> List[LocalizedSequencePosition]:
+        """src/fm_index.rs:516-544 (ascending BWT-row order)"""
+        return [LocalizedSequencePosition(int(a), int(b)) for a, b in self.locate_string_raw(query)[1]]
+
+    def locate_string_raw(self, query):
+        """-> (global positions uint64[n], (seq_idx, local_pos) uint64[n, 2])"""
+        q = _as_bytes(query)
+        hits, gp, n = C.POINTER(_lib.Pos)(), _u64p(), C.c_uint64()
+        _check(self._L.awry_locate(self._h, q, len(q), C.byref(hits), C.byref(gp), C.byref(n)))
+        k = int(n.value)
+        g = np.ctypeslib.as_array(gp, shape=(k,)).copy() if k else np.zeros(0, np.uint64)
+        p = np.ctypeslib.as_array(C.cast(hits, _u64p), shape=(2 * k,)).copy().reshape(-1, 2) if k else np.zeros((0, 2), np.uint64)
+        self._L.awry_free_buffer(hits)
+        self._L.awry_free_buffer(gp)
+        return g, p
+
+    def initial_search_range(self, symbol) -> SearchRange:
+        r = _lib.Range()
+        _check(self._L.awry_initial_range(self._h, ord(symbol) if isinstance(symbol, str) else int(symbol), C.byref(r)))
+        return SearchRange(int(r.start_ptr), int(r.end_ptr))
+
+    def update_range_with_symbol(self, search_range: SearchRange, symbol) -> SearchRange:
+        """src/fm_index.rs:559-582"""
+        r = _lib.Range()
+        _check(self._L.awry_update_range(self._h, _lib.Range(search_range.start_ptr, search_range.end_ptr),
+                                         ord(symbol) if isinstance(symbol, str) else int(symbol), C.byref(r)))
+        return SearchRange(int(r.start_ptr), int(r.end_ptr))
+
+    def backstep(self, search_pointer: int) -> int:
+        """src/fm_index.rs:585-593"""
+        o = C.c_uint64()
+        _check(self._L.awry_backstep(self._h, search_pointer, C.byref(o)))
+        return int(o.value)
+
+    def get_seq_location(self, global_position: int) -> LocalizedSequencePosition:
+        p = _lib.Pos()
+        _check(self._L.awry_get_seq_location(self._h, global_position, C.byref(p)))
+        return LocalizedSequencePosition(int(p.seq_idx), int(p.local_pos))
+
+    # ------------------------------------------------------------------ batch queries
+    def parallel_count_csr(self, qbytes: np.ndarray, qoff: np.ndarray) -> np.ndarray:
+        qb = np.ascontiguousarray(qbytes, dtype=np.uint8)
+        qo = np.ascontiguousarray(qoff, dtype=np.uint64)
+        n = len(qo) - 1
+        out = np.zeros(n, dtype=np.uint64)
+        _check(self._L.awry_count_batch(self._h, qb.ctypes.data, qo.ctypes.data_as(_u64p), n, out.ctypes.data_as(_u64p)))
+        return out
+
+    def parallel_count(self, queries: Iterable) -> np.ndarray:
+        """src/fm_index.rs:455-460: counts in input order"""
+        return self.parallel_count_csr(*pack_queries(queries))
+
+    def parallel_locate_csr(self, qbytes: np.ndarray, qoff: np.ndarray):
+        """-> (hit_off uint64[n+1], global_pos uint64[total], pos uint64[total, 2])"""
+        qb = np.ascontiguousarray(qbytes, dtype=np.uint8)
+        qo = np.ascontiguousarray(qoff, dtype=np.uint64)
+        n = len(qo) - 1
+        off, hits, gp = _u64p(), C.POINTER(_lib.Pos)(), _u64p()
+        _check(self._L.awry_locate_batch(self._h, qb.ctypes.data, qo.ctypes.data_as(_u64p), n, C.byref(off), C.byref(hits), C.byref(gp)))
+        offs = np.ctypeslib.as_array(off, shape=(n + 1,)).copy()
+        tot = int(offs[-1])
+        g = np.ctypeslib.as_array(gp, shape=(tot,)).copy() if tot else np.zeros(0, np.uint64)
+        p = np.ctypeslib.as_array(C.cast(hits, _u64p), shape=(2 * tot,)).copy().reshape(-1, 2) if tot else np.zeros((0, 2), np.uint64)
+        for x in (off, hits, gp):
+            self._L.awry_free_buffer(x)
+        return offs, g, p
+
+    def parallel_locate(self, queries: Iterable) -> List[List[LocalizedSequencePosition]]:
+        """src/fm_index.rs:479-487: outer order = input order, inner order = ascending BWT row"""
+        off, _, p = self.parallel_locate_csr(*pack_queries(queries))
+        return [[LocalizedSequencePosition(int(a), int(b)) for a, b in p[off[i]:off[i + 1]]] for i in range(len(off) - 1)]
+
+    # ------------------------------------------------------------------ device-resident path
+    def dev_malloc(self, nbytes, slot=0) -> int:
+        p = C.c_void_p()
+        _check(self._L.awry_dev_malloc(self._h, slot, nbytes, C.byref(p)))
+        return p.value
+
+    def dev_free(self, ptr, slot=0):
+        _check(self._L.awry_dev_free(self._h, slot, ptr))
+
+    def dev_upload(self, arr: np.ndarray, slot=0) -> int:
+        a = np.ascontiguousarray(arr)
+        p = self.dev_malloc(a.nbytes, slot)
+        _check(self._L.awry_dev_memcpy_h2d(self._h, slot, p, a.ctypes.data, a.nbytes))
+        return p
+
+    def dev_download(self, ptr, shape, dtype, slot=0) -> np.ndarray:
+        out = np.empty(shape, dtype=dtype)
+        _check(self._L.awry_dev_memcpy_d2h(self._h, slot, out.ctypes.data, ptr, out.nbytes))
+        return out
+
+    def dev_memset(self, ptr, value, nbytes, slot=0):
+        _check(self._L.awry_dev_memset(self._h, slot, ptr, value, nbytes))
+
+    def dev_synchronize(self, slot=0):
+        _check(self._L.awry_dev_synchronize(self._h, slot))
+
+    def dev_pack_nt2(self, d_ascii, n, L, d_words, d_bad, stream=None, slot=0):
+        _check(self._L.awry_dev_pack_nt2(self._h, slot, d_ascii, n, L, d_words, d_bad, stream))
+
+    def dev_count_nt2(self, d_words, n, L, d_counts, use_seed=True, stream=None, slot=0):
+        _check(self._L.awry_dev_count_nt2(self._h, slot, d_words, n, L, d_counts, 1 if use_seed else 0, stream))
+
+    def dev_count_nt2_tally(self, d_words, n, L, d_counts, d_tally, use_seed=True, stream=None, slot=0):
+        _check(self._L.awry_dev_count_nt2_tally(self._h, slot, d_words, n, L, d_counts, 1 if use_seed else 0, d_tally, stream))
+
+    def dev_count_ascii(self, d_qbytes, d_qoff, n, d_counts, d_ranges=None, d_status=None, stream=None, slot=0):
+        _check(self._L.awry_dev_count_ascii(self._h, slot, d_qbytes, d_qoff, n, d_counts, d_ranges, d_status, stream))
+
+    def dev_scan_counts(self, d_counts, n, d_hit_off, d_scratch, stream=None, slot=0):
+        _check(self._L.awry_dev_scan_counts(self._h, slot, d_counts, n, d_hit_off, d_scratch, stream))
+
+    def dev_scan_scratch_bytes(self, n) -> int:
+        return int(self._L.awry_dev_scan_scratch_bytes(n))
+
+    def dev_locate(self, d_ranges, d_hit_off, n, total, d_gpos, d_pos=None, stream=None, slot=0):
+        _check(self._L.awry_dev_locate(self._h, slot, d_ranges, d_hit_off, n, total, d_gpos, d_pos, stream))
+
+    def dev_timer_begin(self, stream=None, slot=0):
+        _check(self._L.awry_dev_timer_begin(self._h, slot, stream))
+
+    def dev_timer_end(self, stream=None, slot=0) -> float:
+        ms = C.c_float()
+        _check(self._L.awry_dev_timer_end(self._h, slot, stream, C.byref(ms)))
+        return float(ms.value)
+
+    # convenience: count packed-able fixed-length ACGT k-mers given as uint8[n, L] through the hot kernel
+    def count_kmers_nt2(self, q2d: np.ndarray, use_seed=True, slot=0) -> np.ndarray:
+        q2d = np.ascontiguousarray(q2d, dtype=np.uint8)
+        n, L = q2d.shape
+        d_ascii = self.dev_upload(q2d.reshape(-1), slot)
+        d_words, d_counts, d_bad = self.dev_malloc(8 * n, slot), self.dev_malloc(8 * n, slot), self.dev_malloc(8, slot)
+        try:
+            self.dev_memset(d_bad, 0, 8, slot)
+            self.dev_pack_nt2(d_ascii, n, L, d_words, d_bad, None, slot)
+            self.dev_synchronize(slot)
+            bad = int(self.dev_download(d_bad, (1,), np.uint64, slot)[0])
+            if bad:
+                raise AwryError(ERR_INVALID_QUERY, "%d queries contain bytes outside ACGT; use parallel_count" % bad)
+            self.dev_count_nt2(d_words, n, L, d_counts, use_seed, None, slot)
+            self.dev_synchronize(slot)
+            return self.dev_download(d_counts, (n,), np.uint64, slot)
+        finally:
+            for p in (d_ascii, d_words, d_counts, d_bad):
+                self.dev_free(p, slot)

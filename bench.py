@@ -1,0 +1,262 @@
+#!/usr/bin/env python3
+"""bench.py -- k-mer count throughput of the MI355X FM-index engine (BASELINE.json's metric).
+
+    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+
+One "step" = one pass of the hot path (awry_dev_count_nt2: seeded backward search over packed 31-mers)
+over one batch of synthetic queries per GPU, queries already resident in HBM.  The index is replicated
+per GPU and the query batch is sharded by rank with no data-path collective -> weak scaling.
+Rank 0 prints ONE JSON line with the roofline object (algorithmic bytes from an in-kernel work census,
+HIP-event kernel time) and, at N == 1, the CPU baseline (the oracle = C restatement of the reference's
+rayon/AVX2 path, timed on this host's cores on a bounded sample of the same batch).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (text length without '$', records, N fraction)   -- SURVEY.md 8(d) C1/C2/C3 shapes
+    "ecoli": (4_641_652, 1, 0.0),
+    "chr1": (248_956_422, 1, 0.07),
+    "grch38": (3_100_000_000, 25, 0.05),
+}
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def log(*a):
+    print("[bench]", *a, file=sys.stderr, flush=True)
+
+
+def unpack_nt2(words, L):
+    """uint64[n] packed k-mers -> uint8[n, L] ASCII (letter j in bits 2j..2j+1)"""
+    w = words.astype(np.uint64)
+    out = np.empty((len(w), L), dtype=np.uint8)
+    lut = np.frombuffer(b"ACGT", dtype=np.uint8)
+    for j in range(L):
+        out[:, j] = lut[((w >> np.uint64(2 * j)) & np.uint64(3)).astype(np.int64)]
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default=os.environ.get("AWRY_BENCH_WORKLOAD", "chr1"), choices=sorted(WORKLOADS))
+    ap.add_argument("--text-len", type=int, default=0, help="override the workload's text length")
+    ap.add_argument("--queries", type=int, default=10_000_000, help="queries per GPU per step")
+    ap.add_argument("--qlen", type=int, default=31)
+    ap.add_argument("--seed-k", type=int, default=-1, help="device seed-table k (-1 = library default, 0 = off)")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline duration (0 = skip)")
+    ap.add_argument("--no-variants", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        log("warning: WORLD_SIZE %d != --gpus %d; using WORLD_SIZE" % (world, args.gpus))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    import awry_amd
+    from tests import synth
+
+    n_text, n_rec, n_frac = WORKLOADS[args.workload]
+    if args.text_len:
+        n_text = args.text_len
+    L, nq, K, W = args.qlen, args.queries, args.steps, args.warmup
+
+    # ---- index: same seeded text on every rank, one replica in this rank's HBM
+    t0 = time.time()
+    text, starts, headers = synth.make_text(n_text, 0, 0xA5A50000 + 2, n_rec, n_frac)
+    t1 = time.time()
+    ix = awry_amd.FmIndex.from_text(text, 0, 8, 0, starts, headers)
+    t2 = time.time()
+    ix.set_devices([local_rank])
+    if args.seed_k >= 0:
+        ix.set_seed_kmer_len(args.seed_k)
+    t3 = time.time()
+    if rank == 0:
+        log("text %.1fs, host index build %.1fs, replicate+seed(k=%d) %.1fs, bwt_len=%d" %
+            (t1 - t0, t2 - t1, ix.seed_kmer_len(), t3 - t2, ix.bwt_len()))
+
+    # ---- synthetic query batches, generated on the device: a uniform random L-mer is a uniform 2L-bit integer
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1234 + rank)
+    n_batches = max(1, min(K + W, 8))
+    batches = [torch.randint(0, 1 << (2 * L), (nq,), dtype=torch.int64, device=dev, generator=gen) for _ in range(n_batches)]
+    counts = torch.zeros(nq, dtype=torch.int64, device=dev)
+    tally = torch.zeros(3, dtype=torch.int64, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step(i, seeded=True):
+        ix.dev_count_nt2(batches[i % n_batches].data_ptr(), nq, L, counts.data_ptr(), seeded, stream, 0)
+
+    for i in range(W):
+        step(i)
+    barrier()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t_start = time.perf_counter()
+    ev0.record()
+    for i in range(K):
+        step(W + i)
+    ev1.record()
+    barrier()
+    elapsed = time.perf_counter() - t_start
+    kernel_ms = ev0.elapsed_time(ev1) / K  # HIP events on the stream the kernel runs on
+
+    # ---- work census of the timed batches (same kernel, TALLY variant, untimed)
+    for i in range(K):
+        ix.dev_count_nt2_tally(batches[(W + i) % n_batches].data_ptr(), nq, L, counts.data_ptr(), tally.data_ptr(), True, stream, 0)
+    torch.cuda.synchronize()
+    probes, steps_exec, blocks = [int(x) / K for x in tally.cpu().tolist()]
+    alg_bytes = 16.0 * probes + 104.0 * blocks + nq * (8.0 + 8.0)  # probe 16 B, block 104 B, query 8 B, result 8 B
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed_max = float(t.item())
+    total_q = float(nq) * K * world
+    value = total_q / elapsed_max
+
+    result = {
+        "metric": "k-mer count queries/sec (parallel_count, random %d-mers, index resident in HBM)" % L,
+        "value": value, "unit": "queries/s", "n_gpus": world, "steps": K, "warmup": W,
+        "ms_per_step": 1000.0 * elapsed_max / K, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+        "config": {"workload": "%s-scale synthetic nucleotide text (%d bp, %d record(s), %.0f%% N), %d uniform-random %d-mers per GPU per step, "
+                               "packed 2-bit queries resident in HBM, seed table k=%d, SA ratio 8"
+                               % (args.workload, n_text, n_rec, 100 * n_frac, nq, L, ix.seed_kmer_len()),
+                   "text_len": n_text, "queries_per_gpu_per_step": nq, "query_len": L, "seed_k": ix.seed_kmer_len(),
+                   "sharding": "index replicated per GPU, queries sharded by rank, no collective"},
+        "roofline": {"bound": "hbm", "kernel": "count_nt2_quad_kernel<seed>", "achieved": alg_bytes / (kernel_ms * 1e-3) / 1e9,
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg_bytes / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                     "traffic": None, "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": alg_bytes,
+                     "census_per_launch": {"seed_probes": probes, "steps": steps_exec, "block_reads": blocks}},
+    }
+
+    if rank == 0 and world == 1:
+        extra = {}
+        if not args.no_variants:
+            # the same batch without the seed table (the reference's step schedule minus nothing: every step executed)
+            tally.zero_()
+            for i in range(3):
+                step(i, False)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for i in range(5):
+                step(i, False)
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / 5
+            for i in range(5):
+                ix.dev_count_nt2_tally(batches[i % n_batches].data_ptr(), nq, L, counts.data_ptr(), tally.data_ptr(), False, stream, 0)
+            torch.cuda.synchronize()
+            p2, s2, b2 = [int(x) / 5 for x in tally.cpu().tolist()]
+            ab = 104.0 * b2 + nq * 16.0
+            extra["unseeded"] = {"queries_per_s": nq / (ms * 1e-3), "kernel_ms": ms, "achieved_GBs": ab / (ms * 1e-3) / 1e9,
+                                 "frac": ab / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "steps_per_query": s2 / nq, "block_reads_per_query": b2 / nq}
+            # queries drawn from the text: present => all L - k steps execute
+            ns = min(nq, 2_000_000)
+            present = synth.sampled_queries(text, ns, L, 77)
+            d_ascii = torch.from_numpy(present.reshape(-1)).to(dev)
+            d_words = torch.zeros(ns, dtype=torch.int64, device=dev)
+            d_bad = torch.zeros(1, dtype=torch.int64, device=dev)
+            ix.dev_pack_nt2(d_ascii.data_ptr(), ns, L, d_words.data_ptr(), d_bad.data_ptr(), stream, 0)
+            torch.cuda.synchronize()
+            assert int(d_bad.item()) == 0
+            for _ in range(2):
+                ix.dev_count_nt2(d_words.data_ptr(), ns, L, counts.data_ptr(), True, stream, 0)
+            e0.record()
+            for _ in range(5):
+                ix.dev_count_nt2(d_words.data_ptr(), ns, L, counts.data_ptr(), True, stream, 0)
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / 5
+            assert bool((counts[:ns] >= 1).all()), "a k-mer sampled from the text was not found"
+            tally.zero_()
+            ix.dev_count_nt2_tally(d_words.data_ptr(), ns, L, counts.data_ptr(), tally.data_ptr(), True, stream, 0)
+            torch.cuda.synchronize()
+            p3, s3, b3 = [int(x) for x in tally.cpu().tolist()]
+            ab = 16.0 * p3 + 104.0 * b3 + ns * 16.0
+            extra["present_queries"] = {"queries": ns, "queries_per_s": ns / (ms * 1e-3), "kernel_ms": ms,
+                                        "achieved_GBs": ab / (ms * 1e-3) / 1e9, "frac": ab / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                        "steps_per_query": s3 / ns}
+            # ASCII boundary with on-device packing in the timed region (31 B/query read instead of 8 B)
+            na = min(nq, 5_000_000)
+            asc = torch.from_numpy(unpack_nt2(batches[0][:na].cpu().numpy().view(np.uint64), L).reshape(-1)).to(dev)
+            w2 = torch.zeros(na, dtype=torch.int64, device=dev)
+            for rep in range(2):
+                e0.record()
+                for _ in range(5):
+                    ix.dev_pack_nt2(asc.data_ptr(), na, L, w2.data_ptr(), d_bad.data_ptr(), stream, 0)
+                    ix.dev_count_nt2(w2.data_ptr(), na, L, counts.data_ptr(), True, stream, 0)
+                e1.record()
+                torch.cuda.synchronize()
+            extra["ascii_resident_pack_plus_count"] = {"queries": na, "queries_per_s": na / (e0.elapsed_time(e1) / 5 * 1e-3)}
+        result["variants"] = extra
+
+        if args.cpu_seconds > 0:
+            from oracle import oracle_ffi
+            path = "/tmp/awry_bench_%d.awry" % os.getpid()
+            ts = time.time()
+            ix.save(path)  # .awry v1 in the reference's own layout: 160-B blocks, packed SA, k-mer table
+            oi = oracle_ffi.OracleIndex.load(path)
+            os.remove(path)
+            log("oracle index via .awry round trip: %.1fs" % (time.time() - ts))
+            cores = os.cpu_count() or 1
+            w0 = batches[W % n_batches][:4_000_000].cpu().numpy().view(np.uint64)
+            probe_n = 100_000
+            qb, qo = synth.fixed_to_csr(unpack_nt2(w0[:probe_n], L))
+            tp = time.perf_counter()
+            oi.parallel_count(qb, qo, cores)
+            rate = probe_n / (time.perf_counter() - tp)
+            sample = int(max(probe_n, min(len(w0), rate * args.cpu_seconds)))
+            qb, qo = synth.fixed_to_csr(unpack_nt2(w0[:sample], L))
+            tp = time.perf_counter()
+            ocounts, otally = oi.parallel_count(qb, qo, cores)
+            dt = time.perf_counter() - tp
+            # parity of the timed GPU path against the oracle on the same sample
+            ix.dev_count_nt2(batches[W % n_batches].data_ptr(), nq, L, counts.data_ptr(), True, stream, 0)
+            torch.cuda.synchronize()
+            gcounts = counts[:sample].cpu().numpy().view(np.uint64)
+            parity = bool(np.array_equal(gcounts, ocounts))
+            result["cpu_baseline"] = {"value": sample / dt, "unit": "queries/s", "cores": cores, "kind": "port",
+                                      "sample": "first %d queries of timed batch 0 (same index via .awry v1 round trip), "
+                                                "reference step schedule, %d threads, %.1f s" % (sample, cores, dt),
+                                      "steps_per_query": otally["steps"] / sample,
+                                      "block_reads_per_query": otally["block_reads"] / sample,
+                                      "gpu_matches_oracle_on_sample": parity}
+            if not parity:
+                log("PARITY FAILURE: GPU counts differ from the oracle on the sample")
+                print(json.dumps(result))
+                sys.exit(3)
+
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

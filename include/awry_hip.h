@@ -1,0 +1,159 @@
+/*
+ * awry_hip.h -- C ABI of libawry_hip.so: the MI355X (gfx950) FM-index search engine that stands in for
+ * the query path of the Rust crate AWRY 0.3.1.  Plain pointers and sizes only; no exception crosses.
+ *
+ * Each entry point names the reference interface it replaces (file:line under /root/reference).  The
+ * reference has no FFI of its own -- its boundary is the `pub` surface of `FmIndex` (src/fm_index.rs) --
+ * so a Rust shim crate re-creating that surface binds exactly these symbols.
+ *
+ * There is NO CPU search path in this library: every query entry point runs HIP kernels on the devices
+ * selected with awry_set_devices() and fails with AWRY_ERR_NO_DEVICE / AWRY_ERR_HIP otherwise.
+ */
+#ifndef AWRY_HIP_H
+#define AWRY_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* status codes (0 = OK, < 0 = error class); awry_last_error() has the message */
+enum {
+  AWRY_OK = 0,
+  AWRY_ERR_IO = -1,            /* file could not be opened / read / written                              */
+  AWRY_ERR_FORMAT = -2,        /* not an .awry v1 file, corrupt header, unsupported size                 */
+  AWRY_ERR_INVALID_QUERY = -3, /* empty query, '$' / '#', byte >= 0x80: the reference panics or is UB     */
+  AWRY_ERR_HIP = -4,           /* a HIP runtime call or kernel failed                                    */
+  AWRY_ERR_OOM = -5,
+  AWRY_ERR_ARG = -6,           /* null pointer, bad alphabet id, bad device id ...                       */
+  AWRY_ERR_NO_DEVICE = -7      /* query issued before awry_set_devices(), or no GPU present              */
+};
+
+enum { AWRY_NUCLEOTIDE = 0, AWRY_AMINO = 1 }; /* SymbolAlphabet, src/alphabet.rs:28-31,48-61 */
+
+typedef struct awry_index awry_index_t; /* opaque: host copy of the index + one replica per selected GPU */
+
+/* == LocalizedSequencePosition, src/sequence_index.rs:31-35 */
+typedef struct { uint64_t seq_idx, local_pos; } awry_pos_t;
+
+/* == SearchRange, src/search.rs:25-28 (closed interval of BWT rows; empty iff start_ptr > end_ptr) */
+typedef struct { uint64_t start_ptr, end_ptr; } awry_range_t;
+
+/* == FmBuildArgs, src/fm_index.rs:78-96 */
+typedef struct {
+  const char *input_path;  /* input_file_src: FASTA or FASTQ                                              */
+  const char *sa_tmp_path; /* suffix_array_output_src: accepted for signature parity, unused (no .sufr)   */
+  uint64_t sa_ratio;       /* suffix_array_compression_ratio, 0 => 8 (src/fm_index.rs:122)                */
+  uint8_t kmer_len;        /* lookup_table_kmer_len, 0 => 10 nt / 4 aa (src/kmer_lookup_table.rs:23-24)   */
+  uint8_t alphabet;        /* AWRY_NUCLEOTIDE / AWRY_AMINO                                                */
+  uint64_t max_query_len;  /* accepted for signature parity; the full suffix array is always built        */
+  uint8_t remove_tmp;      /* remove_intermediate_suffix_array_file: no intermediate file exists          */
+} awry_build_args_t;
+
+/* ---- construction / persistence ------------------------------------------------------------------ */
+/* FmIndex::new, src/fm_index.rs:142-268 */
+int awry_build(const awry_build_args_t *args, awry_index_t **out);
+/* same, from an in-memory text that follows the reference's text model (records joined by 'N'/'X', one
+ * trailing '$', src/fm_index.rs:148-153,220-223); seq_starts/headers describe the records */
+int awry_build_from_text(const uint8_t *text, uint64_t bwt_len, int alphabet, uint64_t sa_ratio, uint8_t kmer_len,
+                         const uint64_t *seq_starts, const char *const *headers, uint64_t nseq, awry_index_t **out);
+/* FmIndex::load / FmIndex::save, src/fm_index_file.rs:132,42 (.awry v1, byte-compatible) */
+int awry_load(const char *path, awry_index_t **out);
+int awry_save(awry_index_t *idx, const char *path); /* needs a device: fills the k-mer table on the GPU */
+void awry_free(awry_index_t *idx);
+
+/* ---- device placement (replaces rayon's global pool, src/fm_index.rs:455-487) ---------------------- */
+/* replicate the index into the HBM of each listed device and build its seed table; batches are then
+ * sharded contiguously over the replicas.  n_devices == 0 is an error: there is no CPU backend. */
+int awry_set_devices(awry_index_t *idx, const int *device_ids, int n_devices);
+/* device-side seed-table length (performance knob only; results do not depend on it).  0 disables,
+ * -1 picks the default.  Takes effect immediately on all replicas. */
+int awry_set_seed_kmer_len(awry_index_t *idx, int k);
+int awry_seed_kmer_len(const awry_index_t *idx);
+int awry_num_devices(const awry_index_t *idx);
+
+/* ---- batch queries --------------------------------------------------------------------------------- */
+/* FmIndex::parallel_count, src/fm_index.rs:455-460.  Query i = qbytes[qoff[i] .. qoff[i+1]); results in
+ * input order in caller-owned counts_out[n].  Any undefined query => AWRY_ERR_INVALID_QUERY. */
+int awry_count_batch(awry_index_t *idx, const uint8_t *qbytes, const uint64_t *qoff, uint64_t n, uint64_t *counts_out);
+/* FmIndex::parallel_locate, src/fm_index.rs:479-487.  CSR output, library-allocated (awry_free_buffer):
+ * hits of query i are [hit_off[i], hit_off[i+1]) in ascending BWT-row order (src/fm_index.rs:521);
+ * global_pos (nullable) receives (SA sample + steps) % bwt_len (src/fm_index.rs:534). */
+int awry_locate_batch(awry_index_t *idx, const uint8_t *qbytes, const uint64_t *qoff, uint64_t n,
+                      uint64_t **hit_off_out, awry_pos_t **hits_out, uint64_t **global_pos_out);
+void awry_free_buffer(void *p);
+
+/* ---- scalar conveniences (each launches on replica 0) ---------------------------------------------- */
+int awry_count(awry_index_t *idx, const uint8_t *q, uint64_t len, uint64_t *count);          /* count_string :499  */
+int awry_search_range(awry_index_t *idx, const uint8_t *q, uint64_t len, awry_range_t *out); /* :402-438          */
+int awry_locate(awry_index_t *idx, const uint8_t *q, uint64_t len, awry_pos_t **hits_out,
+                uint64_t **global_pos_out, uint64_t *n_hits);                                /* locate_string :516 */
+int awry_initial_range(const awry_index_t *idx, uint8_t symbol_ascii, awry_range_t *out);    /* :383-385          */
+int awry_update_range(awry_index_t *idx, awry_range_t in, uint8_t symbol_ascii, awry_range_t *out); /* :559-582   */
+int awry_backstep(awry_index_t *idx, uint64_t row, uint64_t *out);                           /* :585-593          */
+int awry_get_seq_location(const awry_index_t *idx, uint64_t global_pos, awry_pos_t *out);    /* sequence_index.rs:108 */
+
+/* ---- accessors (src/fm_index.rs:302-399) ------------------------------------------------------------ */
+int awry_alphabet(const awry_index_t *idx);
+uint64_t awry_bwt_len(const awry_index_t *idx);
+uint64_t awry_version(const awry_index_t *idx);
+uint64_t awry_sa_ratio(const awry_index_t *idx);
+uint8_t awry_kmer_len(const awry_index_t *idx);
+const uint64_t *awry_prefix_sums(const awry_index_t *idx, uint64_t *len);
+uint64_t awry_num_sequences(const awry_index_t *idx);
+uint64_t awry_sequence_start(const awry_index_t *idx, uint64_t i);
+const char *awry_sequence_header(const awry_index_t *idx, uint64_t i);
+uint64_t awry_sentinel_row(const awry_index_t *idx);
+/* device-layout BWT blocks and packed SA words of the host copy (layout.h); for tests and tooling */
+const uint64_t *awry_block_words(const awry_index_t *idx, uint64_t *nwords);
+const uint64_t *awry_sa_words(const awry_index_t *idx, uint64_t *nwords);
+/* one block converted to the reference layout (planes, then 8 / 24 milestones), src/bwt.rs:12-25 */
+int awry_block_reference_layout(const awry_index_t *idx, uint64_t block, uint64_t *out, uint64_t out_words);
+
+const char *awry_last_error(void); /* thread-local message of the last non-zero status */
+
+/* ---- host utilities ----------------------------------------------------------------------------------- */
+/* suffix array of a byte text ending in '$' (host SA-IS; stands in for libsufr, src/fm_index.rs:156-181) */
+int awry_host_suffix_array(const uint8_t *text, uint64_t n, uint64_t *sa_out);
+uint8_t awry_symbol_index(int alphabet, uint8_t ascii); /* Symbol::new_ascii(..).index(), src/alphabet.rs:109,152 */
+
+/* ---- device-resident API: pointers are device memory on replica `slot`'s GPU, work is queued on
+ *      `stream` (a hipStream_t, NULL = default stream) and NOT synchronised --------------------------------- */
+int awry_replica_device(const awry_index_t *idx, int slot);
+/* fixed-length ACGT k-mers (L <= 32), ASCII n*L bytes -> n packed u64 words (letter j in bits 2j..2j+1);
+ * *d_bad (u64 on device, caller-zeroed) counts queries with other bytes */
+int awry_dev_pack_nt2(awry_index_t *idx, int slot, const void *d_ascii, uint64_t n, int L, void *d_words,
+                      void *d_bad, void *stream);
+/* the hot kernel: count n packed k-mers -> u64 counts.  use_seed != 0 starts from the seed table */
+int awry_dev_count_nt2(awry_index_t *idx, int slot, const void *d_words, uint64_t n, int L, void *d_counts,
+                       int use_seed, void *stream);
+/* same kernel with a work census for the roofline figure: d_tally[3] (u64, caller-zeroed) += {seed probes,
+ * executed steps, distinct BWT blocks ranked} -- the tallies SURVEY.md 8(d) prices at 16 B / 104 B each */
+int awry_dev_count_nt2_tally(awry_index_t *idx, int slot, const void *d_words, uint64_t n, int L, void *d_counts,
+                             int use_seed, void *d_tally, void *stream);
+/* generic path: ASCII queries + u64 offsets[n+1] -> counts[n], optional ranges[2n] (start,end) and status[n] bytes */
+int awry_dev_count_ascii(awry_index_t *idx, int slot, const void *d_qbytes, const void *d_qoff, uint64_t n,
+                         void *d_counts, void *d_ranges, void *d_status, void *stream);
+/* exclusive scan of counts[n] -> hit_off[n+1] (d_scratch: awry_dev_scan_scratch_bytes(n) bytes) */
+uint64_t awry_dev_scan_scratch_bytes(uint64_t n);
+int awry_dev_scan_counts(awry_index_t *idx, int slot, const void *d_counts, uint64_t n, void *d_hit_off,
+                         void *d_scratch, void *stream);
+/* backtrace total hits: ranges[2n], hit_off[n+1] -> global_pos[total], pos[total] (nullable) */
+int awry_dev_locate(awry_index_t *idx, int slot, const void *d_ranges, const void *d_hit_off, uint64_t n,
+                    uint64_t total, void *d_global_pos, void *d_pos, void *stream);
+/* plumbing for callers without a HIP binding of their own */
+int awry_dev_malloc(awry_index_t *idx, int slot, uint64_t bytes, void **d_out);
+int awry_dev_free(awry_index_t *idx, int slot, void *d);
+int awry_dev_memcpy_h2d(awry_index_t *idx, int slot, void *d_dst, const void *h_src, uint64_t bytes);
+int awry_dev_memcpy_d2h(awry_index_t *idx, int slot, void *h_dst, const void *d_src, uint64_t bytes);
+int awry_dev_memset(awry_index_t *idx, int slot, void *d_dst, int value, uint64_t bytes);
+int awry_dev_synchronize(awry_index_t *idx, int slot);
+/* time a region on `stream` with HIP events: begin/end record, elapsed synchronises and returns ms */
+int awry_dev_timer_begin(awry_index_t *idx, int slot, void *stream);
+int awry_dev_timer_end(awry_index_t *idx, int slot, void *stream, float *ms_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AWRY_HIP_H */

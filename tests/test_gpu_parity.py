@@ -1,0 +1,190 @@
+"""GPU parity tests (run on a real MI355X via `pytest -m gpu`): the HIP path, called through the C ABI of
+libawry_hip.so, against the committed golden vectors and the CPU oracle on the same seeded inputs, plus
+size-independent properties at larger sizes.  Bar: bit-exact (integer work)."""
+import ctypes as C
+import glob
+import json
+import os
+
+import numpy as np
+import pytest
+
+from awry_amd.fm_index import ERR_INVALID_QUERY, AwryError, FmIndex, SearchRange
+from tests import synth
+
+pytestmark = pytest.mark.gpu
+GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.json")))
+
+
+def gpu_index(text, alphabet, ratio=8, kmer_len=0, st=(0,), hd=("seq0",), devices=(0,)):
+    return FmIndex.from_text(text, alphabet, ratio, kmer_len, st, hd).set_devices(list(devices))
+
+
+@pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p)[:-5] for p in GOLDEN])
+@pytest.mark.parametrize("sa_ratio", [8, 1, 5])
+def test_golden_vectors(path, sa_ratio):
+    g = json.load(open(path))
+    ix = gpu_index(g["text"], g["alphabet"], sa_ratio, 0, g["seq_starts"], g["headers"])
+    qs = [r["q"] for r in g["queries"]]
+    counts = ix.parallel_count(qs)
+    assert counts.tolist() == [r["count"] for r in g["queries"]]
+    off, gpos, pos = ix.parallel_locate_csr(*__import__("awry_amd").fm_index.pack_queries(qs))
+    starts = np.array(g["seq_starts"], dtype=np.uint64)
+    for i, r in enumerate(g["queries"]):
+        mine = gpos[off[i]:off[i + 1]]
+        assert sorted(mine.tolist()) == r["pos"], r["q"]
+        si = np.searchsorted(starts, mine, side="right") - 1
+        assert np.array_equal(pos[off[i]:off[i + 1], 0], si.astype(np.uint64))
+        assert np.array_equal(pos[off[i]:off[i + 1], 1], mine - starts[si])
+    for r in g["queries"][:25]:  # scalar entry points
+        assert ix.count_string(r["q"]) == r["count"]
+        assert sorted(p.local_position + int(starts[p.sequence_idx]) for p in ix.locate_string(r["q"])) == r["pos"]
+
+
+def mixed_queries(text, alphabet, seed):
+    rng = np.random.default_rng(seed)
+    qs = []
+    for L in (1, 2, 3, 4, 7, 9, 10, 11, 15, 24, 31, 32, 33, 50, 101):
+        qs += [bytes(q) for q in synth.random_queries(12, L, alphabet, seed + L)]
+        qs += [bytes(q) for q in synth.sampled_queries(text, 12, L, seed + 100 + L, False, alphabet)]
+    amb = b"N" if alphabet == 0 else b"X"
+    qs += [amb, amb * 2, amb * 5, b"A" + amb, amb + b"A", b"acg" if alphabet == 0 else b"mkv", b"ACGU" if alphabet == 0 else b"BZJ"]
+    qs += [q.lower() for q in qs[:20]]
+    order = rng.permutation(len(qs))
+    return [qs[i] for i in order]
+
+
+@pytest.mark.parametrize("alphabet,n,recs,nfrac,ratio", [(0, 300000, 5, 0.07, 8), (1, 150000, 60, 0.01, 8), (0, 70000, 1, 0.0, 3)])
+def test_count_and_locate_match_oracle(oracle, alphabet, n, recs, nfrac, ratio):
+    text, st, hd = synth.make_text(n, alphabet, 11, recs, nfrac)
+    ix = gpu_index(text, alphabet, ratio, 0, st, hd)
+    oi = oracle.OracleIndex.from_text(text, alphabet, ratio, 0, st, hd)
+    qs = [q for q in mixed_queries(text, alphabet, 5) if len(q) <= n]
+    qb, qo = __import__("awry_amd").fm_index.pack_queries(qs)
+    ocounts, _ = oi.parallel_count(qb, qo, 4)
+    assert np.array_equal(ix.parallel_count_csr(qb, qo), ocounts)
+    # keep locate output bounded: drop queries with huge hit lists (single letters)
+    keep = [i for i in range(len(qs)) if ocounts[i] <= 5000]
+    qb2, qo2 = __import__("awry_amd").fm_index.pack_queries([qs[i] for i in keep])
+    ooff, ogpos, opos, _ = oi.parallel_locate(qb2, qo2, 4)
+    off, gpos, pos = ix.parallel_locate_csr(qb2, qo2)
+    assert np.array_equal(off, ooff)
+    assert np.array_equal(gpos, ogpos)  # same order too: ascending BWT row, src/fm_index.rs:521
+    assert np.array_equal(pos, opos)
+    for q in qs[:40]:
+        if oi.count_string(q):
+            r = ix.search_range(q)
+            assert (r.start_ptr, r.end_ptr) == oi.search_range(q)
+
+
+@pytest.mark.parametrize("n,recs,nfrac", [(200000, 1, 0.0), (400000, 3, 0.07)])
+def test_packed_kmer_kernel_matches_oracle(oracle, n, recs, nfrac):
+    """the hot quad kernel (packed 2-bit k-mers, seed table on/off) against the oracle and the generic kernel"""
+    text, st, hd = synth.make_text(n, 0, 23, recs, nfrac)
+    ix = gpu_index(text, 0, 8, 0, st, hd)
+    oi = oracle.OracleIndex.from_text(text, 0, 8, 0, st, hd)
+    for L in (1, 2, 5, 8, 9, 12, 16, 21, 31, 32):
+        q2d = np.concatenate([synth.random_queries(700, L, 0, L), synth.sampled_queries(text, 700, L, 50 + L)])
+        qb, qo = synth.fixed_to_csr(q2d)
+        want, _ = oi.parallel_count(qb, qo, 4)
+        for k in (-1, 0, 1, 4, 7):
+            ix.set_seed_kmer_len(k)
+            assert np.array_equal(ix.count_kmers_nt2(q2d, True), want), (L, k)
+        assert np.array_equal(ix.count_kmers_nt2(q2d, False), want), L
+        assert np.array_equal(ix.parallel_count_csr(qb, qo), want), L
+    with pytest.raises(AwryError) as e:  # N is not packable: callers must take the generic path
+        ix.count_kmers_nt2(np.frombuffer(b"ACGNACGT", dtype=np.uint8).reshape(2, 4))
+    assert e.value.code == ERR_INVALID_QUERY
+
+
+def test_scalar_entry_points_match_oracle(oracle):
+    text, st, hd = synth.make_text(5000, 0, 9, 3, 0.05)
+    ix = gpu_index(text, 0, 4, 0, st, hd)
+    oi = oracle.OracleIndex.from_text(text, 0, 4, 0, st, hd)
+    rng = np.random.default_rng(1)
+    for row in rng.integers(0, len(text), 60).tolist() + [0, len(text) - 1, ix.sentinel_row()]:
+        assert ix.backstep(int(row)) == oi.backstep(int(row))
+    for ch, idx in (("A", 1), ("C", 2), ("G", 3), ("N", 4), ("T", 5), ("t", 5), ("U", 5), ("R", 4)):
+        r0 = ix.initial_search_range(ch)
+        assert (r0.start_ptr, r0.end_ptr) == oi.initial_search_range(idx)
+        for ch2, idx2 in (("A", 1), ("C", 2), ("G", 3), ("N", 4), ("T", 5)):
+            r1 = ix.update_range_with_symbol(r0, ch2)
+            assert (r1.start_ptr, r1.end_ptr) == oi.update_range_with_symbol(r0.start_ptr, r0.end_ptr, idx2)
+    aa_text, st, hd = synth.make_text(4000, 1, 3, 4)
+    ax = gpu_index(aa_text, 1, 8, 0, st, hd)
+    ao = oracle.OracleIndex.from_text(aa_text, 1, 8, 0, st, hd)
+    for row in rng.integers(0, len(aa_text), 60).tolist():
+        assert ax.backstep(int(row)) == ao.backstep(int(row))
+    for i, ch in enumerate("ACDEFGHIKLMNPQRSTVWXY", start=1):
+        r0 = ax.initial_search_range(ch)
+        assert (r0.start_ptr, r0.end_ptr) == ao.initial_search_range(i)
+        r1 = ax.update_range_with_symbol(r0, "L")
+        assert (r1.start_ptr, r1.end_ptr) == ao.update_range_with_symbol(r0.start_ptr, r0.end_ptr, 10)
+
+
+def test_undefined_queries_are_rejected():
+    """documented deviation: where the reference panics / is UB the call returns INVALID_QUERY"""
+    text, st, hd = synth.make_text(2000, 0, 2)
+    ix = gpu_index(text, 0, 8, 0, st, hd)
+    for bad in ([b""], [b"ACGT", b"AC$T"], [b"#"], [b"ACGT", b"AC\xc3\xa9"]):
+        with pytest.raises(AwryError) as e:
+            ix.parallel_count(bad)
+        assert e.value.code == ERR_INVALID_QUERY
+        with pytest.raises(AwryError) as e:
+            ix.parallel_locate(bad)
+        assert e.value.code == ERR_INVALID_QUERY
+    assert ix.parallel_count([]).tolist() == []
+    assert ix.parallel_locate([]) == []
+    assert ix.count_string("A" * 3000) == 0  # longer than the text
+
+
+@pytest.mark.parametrize("alphabet,kmer_len", [(0, 0), (0, 4), (1, 0), (1, 3)])
+def test_save_is_byte_identical_to_reference_format(oracle, tmp_path, alphabet, kmer_len):
+    """.awry v1 incl. the reference's partially populated k-mer table (src/kmer_lookup_table.rs:121-167)"""
+    text, st, hd = synth.make_text(20000, alphabet, 13, 6, 0.04)
+    ix = gpu_index(text, alphabet, 8, kmer_len, st, hd)
+    oi = oracle.OracleIndex.from_text(text, alphabet, 8, kmer_len, st, hd)
+    a, b = str(tmp_path / "a.awry"), str(tmp_path / "b.awry")
+    ix.save(a)
+    oi.save(b)
+    assert open(a, "rb").read() == open(b, "rb").read()
+    again = FmIndex.load(a).set_devices([0])
+    q = synth.sampled_queries(text, 200, 9, 3, False, alphabet)
+    qb, qo = synth.fixed_to_csr(q)
+    assert np.array_equal(again.parallel_count_csr(qb, qo), ix.parallel_count_csr(qb, qo))
+    c = str(tmp_path / "c.awry")
+    again.save(c)  # a loaded index re-saves byte-identically (save_load_equality_test, src/fm_index.rs:1046)
+    assert open(c, "rb").read() == open(a, "rb").read()
+
+
+def test_query_sharding_over_replicas_keeps_input_order(oracle):
+    """two replicas (both on GPU 0 here): contiguous shards, concatenated in input order"""
+    text, st, hd = synth.make_text(120000, 0, 4, 2, 0.03)
+    one = gpu_index(text, 0, 8, 0, st, hd, devices=(0,))
+    two = gpu_index(text, 0, 8, 0, st, hd, devices=(0, 0, 0))
+    assert two.num_devices() == 3
+    q2d = np.concatenate([synth.random_queries(2001, 14, 0, 1), synth.sampled_queries(text, 2000, 14, 2)])
+    qb, qo = synth.fixed_to_csr(q2d)
+    assert np.array_equal(one.parallel_count_csr(qb, qo), two.parallel_count_csr(qb, qo))
+    a, b = one.parallel_locate_csr(qb, qo), two.parallel_locate_csr(qb, qo)
+    assert all(np.array_equal(x, y) for x, y in zip(a, b))
+
+
+def test_medium_scale_properties():
+    """size-independent properties at 2e7 symbols (the oracle is not needed): every located position really
+    holds the query; count == number of locations; sampled queries are present; locations are distinct."""
+    n, L = 20_000_000, 31
+    text, st, hd = synth.make_text(n, 0, 77, 1, 0.07)
+    ix = gpu_index(text, 0, 8, 0, st, hd)
+    q2d = np.concatenate([synth.sampled_queries(text, 20000, L, 5), synth.random_queries(20000, L, 0, 6)])
+    qb, qo = synth.fixed_to_csr(q2d)
+    counts = ix.parallel_count_csr(qb, qo)
+    assert (counts[:20000] >= 1).all()
+    assert np.array_equal(counts, ix.count_kmers_nt2(q2d, True)) and np.array_equal(counts, ix.count_kmers_nt2(q2d, False))
+    off, gpos, pos = ix.parallel_locate_csr(qb, qo)
+    assert np.array_equal(np.diff(off), counts)
+    qi = np.repeat(np.arange(len(q2d)), counts.astype(np.int64))
+    win = text[gpos.astype(np.int64)[:, None] + np.arange(L)[None, :]]
+    assert np.array_equal(win, q2d[qi])
+    assert len(np.unique(gpos + qi.astype(np.uint64) * np.uint64(n + 1))) == len(gpos)
+    assert (pos[:, 0] == 0).all() and np.array_equal(pos[:, 1], gpos)

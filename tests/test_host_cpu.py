@@ -1,0 +1,147 @@
+"""CPU-only checks of the product's host logic and of the C-ABI boundary (no kernel launches):
+the library loads and exports every declared symbol, refuses to search without a GPU, and its host-side
+index construction (suffix array, device-layout packing, .awry reader) agrees with the oracle bit for bit."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import awry_amd
+from awry_amd import _lib
+from awry_amd.fm_index import ERR_ARG, ERR_FORMAT, ERR_IO, ERR_NO_DEVICE, AwryError, FmBuildArgs, FmIndex
+from tests import synth
+
+
+def test_library_exports_every_declared_symbol():
+    L = awry_amd.load_library()
+    names = _lib.header_symbols()
+    assert len(names) >= 45
+    missing = [n for n in names if not hasattr(L, n)]
+    assert not missing, missing
+
+
+def test_no_cpu_search_path():
+    """queries before set_devices() fail loudly; set_devices() without a GPU fails loudly"""
+    text, st, hd = synth.make_text(300, 0, 1)
+    ix = FmIndex.from_text(text, 0, 8, 0, st, hd)
+    with pytest.raises(AwryError) as e:
+        ix.count_string("ACGT")
+    assert e.value.code == ERR_NO_DEVICE
+    with pytest.raises(AwryError) as e:
+        ix.parallel_locate(["ACGT"])
+    assert e.value.code == ERR_NO_DEVICE
+    with pytest.raises(AwryError) as e:
+        ix.set_devices([])
+    assert e.value.code == ERR_NO_DEVICE
+    import shutil
+    if not os.path.exists("/dev/kfd"):
+        with pytest.raises(AwryError) as e:
+            ix.set_devices([0])
+        assert e.value.code in (ERR_NO_DEVICE, -4)
+
+
+def test_symbol_index_map_matches_oracle(oracle):
+    L, O = awry_amd.load_library(), oracle.lib()
+    for alpha in (0, 1):
+        for a in range(256):
+            assert L.awry_symbol_index(alpha, a) == O.orc_ascii_to_index(alpha, a), (alpha, a)
+
+
+@pytest.mark.parametrize("alphabet,n,recs,nfrac,seed", [
+    (0, 1, 1, 0, 0), (0, 2, 1, 0, 1), (0, 7, 1, 0, 2), (0, 1000, 1, 0, 3), (0, 5000, 6, 0.2, 4),
+    (1, 3000, 5, 0.05, 5), (0, 70000, 3, 0.07, 6), (1, 20000, 40, 0.0, 7)])
+def test_host_suffix_array_matches_oracle(oracle, alphabet, n, recs, nfrac, seed):
+    text, _, _ = synth.make_text(n, alphabet, seed, recs, nfrac)
+    sa = np.zeros(len(text), dtype=np.uint64)
+    rc = awry_amd.load_library().awry_host_suffix_array(text.ctypes.data, len(text), sa.ctypes.data_as(C.POINTER(C.c_uint64)))
+    assert rc == 0
+    assert np.array_equal(sa, oracle.suffix_array(text))
+
+
+def test_host_suffix_array_degenerate_texts(oracle):
+    L = awry_amd.load_library()
+    for t in (b"$", b"A$", b"AAAAAAAAAAAAAAAA$", b"NNNNNNNNNNNNNNNNNNNNNNNNNNNNNNNNN$", b"ACACACACACACACAC$", b"TTTTGGGGCCCCAAAA$",
+              b"ACGTNACGTNACGTN$", b"GATTACAGATTACAGATTACA$"):
+        a = np.frombuffer(t, dtype=np.uint8)
+        sa = np.zeros(len(a), dtype=np.uint64)
+        assert L.awry_host_suffix_array(a.ctypes.data, len(a), sa.ctypes.data_as(C.POINTER(C.c_uint64))) == 0
+        assert np.array_equal(sa, oracle.suffix_array(a)), t
+
+
+@pytest.mark.parametrize("alphabet,n,recs,nfrac,ratio,seed", [
+    (0, 1847, 1, 0, 8, 0), (1, 300, 1, 0, 8, 999), (0, 30000, 5, 0.07, 8, 3), (1, 9000, 20, 0.02, 3, 4),
+    (0, 255, 1, 0, 1, 5), (0, 256, 2, 0, 7, 6), (0, 511, 1, 0.3, 16, 7), (0, 100000, 1, 0, 8, 8)])
+def test_host_build_matches_oracle_bit_for_bit(oracle, alphabet, n, recs, nfrac, ratio, seed):
+    """planes + milestones (reference layout), packed sampled SA and prefix sums: src/fm_index.rs:203-240"""
+    text, st, hd = synth.make_text(n, alphabet, seed, recs, nfrac)
+    ix = FmIndex.from_text(text, alphabet, ratio, 0, st, hd)
+    oi = oracle.OracleIndex.from_text(text, alphabet, ratio, 0, st, hd)
+    assert ix.bwt_len() == oi.bwt_len() == n + 1 and ix.alphabet() == alphabet and ix.version_number() == 1
+    assert ix.suffix_array_compression_ratio() == ratio and ix.lookup_table_kmer_len() == oi.kmer_len()
+    assert np.array_equal(ix.prefix_sums(), oi.prefix_sums())
+    assert np.array_equal(ix.sa_words(), oi.sa_words())
+    assert np.array_equal(ix.reference_block_words(), oi.block_words())
+    assert ix.sequences() == oi.sequences()
+    assert oi.symbol_at(ix.sentinel_row()) == 0
+
+
+@pytest.mark.parametrize("alphabet", [0, 1])
+def test_load_reference_format_file(oracle, tmp_path, alphabet):
+    """an .awry v1 file written by the oracle's restatement of src/fm_index_file.rs:42-106 loads identically"""
+    text, st, hd = synth.make_text(6000, alphabet, 31, 4, 0.05)
+    oi = oracle.OracleIndex.from_text(text, alphabet, 5, 3, st, hd)
+    p = str(tmp_path / "o.awry")
+    oi.save(p)
+    ix = FmIndex.load(p)
+    built = FmIndex.from_text(text, alphabet, 5, 3, st, hd)
+    assert ix.bwt_len() == oi.bwt_len() and ix.alphabet() == alphabet and ix.lookup_table_kmer_len() == 3
+    assert ix.suffix_array_compression_ratio() == 5 and ix.sequences() == oi.sequences()
+    assert np.array_equal(ix.prefix_sums(), oi.prefix_sums()) and np.array_equal(ix.sa_words(), oi.sa_words())
+    assert np.array_equal(ix.reference_block_words(), oi.block_words())
+    assert np.array_equal(ix.device_block_words(), built.device_block_words())
+    assert ix.sentinel_row() == built.sentinel_row()
+
+
+def test_load_rejects_bad_files(tmp_path):
+    p = str(tmp_path / "bad.awry")
+    open(p, "wb").write(b"not an index at all, definitely")
+    with pytest.raises(AwryError) as e:
+        FmIndex.load(p)
+    assert e.value.code == ERR_FORMAT
+    open(p, "wb").write(b"AWRY-Index\n" + (1).to_bytes(8, "little") + (8).to_bytes(8, "little"))
+    with pytest.raises(AwryError) as e:
+        FmIndex.load(p)
+    assert e.value.code in (ERR_IO, ERR_FORMAT)
+    with pytest.raises(AwryError) as e:
+        FmIndex.load(str(tmp_path / "missing.awry"))
+    assert e.value.code == ERR_IO
+
+
+def test_build_from_fasta_and_fastq(oracle, tmp_path):
+    """FmIndex::new text model: records joined by 'N', trailing '$' (src/fm_index.rs:148-153)"""
+    text, st, hd = synth.make_text(2500, 0, 77, 6)
+    fa = str(tmp_path / "x.fa")
+    synth.write_fasta(fa, text, st, hd, 70)
+    a = FmIndex.new(FmBuildArgs(fa, None, None, None, 0, None, True))
+    b = FmIndex.from_text(text, 0, 8, 0, st, hd)
+    assert np.array_equal(a.device_block_words(), b.device_block_words()) and a.sequences() == b.sequences()
+    assert np.array_equal(a.sa_words(), b.sa_words()) and a.lookup_table_kmer_len() == 10
+    fq = str(tmp_path / "x.fq")
+    ends = [s - 1 for s in st[1:]] + [len(text) - 1]
+    with open(fq, "wb") as f:
+        for s, e, h in zip(st, ends, hd):
+            f.write(b"@" + h.encode() + b" extra\n" + bytes(text[s:e]).lower() + b"\n+\n" + b"I" * (e - s) + b"\n")
+    c = FmIndex.new(FmBuildArgs(fq, alphabet=0))
+    assert np.array_equal(c.device_block_words(), b.device_block_words()) and c.sequences() == b.sequences()
+    with pytest.raises(AwryError) as e:
+        FmIndex.new(FmBuildArgs(str(tmp_path / "nope.fa")))
+    assert e.value.code == ERR_IO
+
+
+def test_argument_errors():
+    with pytest.raises(AwryError) as e:
+        FmIndex.from_text(b"ACGT", 0)  # no trailing '$'
+    assert e.value.code in (ERR_IO, ERR_ARG)
+    with pytest.raises(AwryError):
+        FmIndex.from_text(b"ACGT$", 2)

@@ -70,6 +70,7 @@ def load_library():
     sig("awry_last_error", cp)
     sig("awry_build", i32, C.POINTER(BuildArgs), vpp)
     sig("awry_build_from_text", i32, vp, u64, i32, u64, u8, u64p, C.POINTER(cp), u64, vpp)
+    sig("awry_build_from_text_on", i32, vp, u64, i32, u64, u8, u64p, C.POINTER(cp), u64, i32, vpp)
     sig("awry_load", i32, cp, vpp)
     sig("awry_save", i32, vp, cp)
     sig("awry_free", None, vp)

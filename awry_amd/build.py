@@ -16,7 +16,7 @@ LIBDIR = os.path.join(HERE, "lib")
 SO = os.path.join(LIBDIR, "libawry_hip.so")
 ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
 HIPCC = os.path.join(ROCM, "bin", "hipcc")
-SOURCES = ["awry_hip.hip", "host_index.cpp"]
+SOURCES = ["awry_hip.hip", "sa_builder.hip", "host_index.cpp"]
 HEADERS = ["kernels.hip.h", "layout.h", "alphabet.h", "host_index.h", "sais.hpp", os.path.join("..", "..", "include", "awry_hip.h")]
 
 
@@ -38,8 +38,9 @@ def build(force=False, verbose=False):
     common = ["-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
     cmds = [
         [HIPCC, "--offload-arch=gfx950", "-march=x86-64-v3"] + common + ["-c", os.path.join(CSRC, "awry_hip.hip"), "-o", os.path.join(obj, "awry_hip.o")],
+        [HIPCC, "--offload-arch=gfx950", "-march=x86-64-v3"] + common + ["-c", os.path.join(CSRC, "sa_builder.hip"), "-o", os.path.join(obj, "sa_builder.o")],
         ["g++", "-march=x86-64-v3"] + common + ["-c", os.path.join(CSRC, "host_index.cpp"), "-o", os.path.join(obj, "host_index.o")],
-        [HIPCC, "--offload-arch=gfx950", "-shared", "-o", SO, os.path.join(obj, "awry_hip.o"), os.path.join(obj, "host_index.o"),
+        [HIPCC, "--offload-arch=gfx950", "-shared", "-o", SO, os.path.join(obj, "awry_hip.o"), os.path.join(obj, "sa_builder.o"), os.path.join(obj, "host_index.o"),
          "-lpthread", "-Wl,-rpath," + os.path.join(ROCM, "lib")],
     ]
     for c in cmds:

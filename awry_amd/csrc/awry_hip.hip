@@ -432,17 +432,50 @@ extern "C" {
 
 const char* awry_last_error(void) { return g_last_error.c_str(); }
 
-int awry_build_from_text(const uint8_t* text, uint64_t bwt_len, int alphabet, uint64_t sa_ratio, uint8_t kmer_len,
-                         const uint64_t* seq_starts, const char* const* headers, uint64_t nseq, awry_index_t** out) {
+// build_device: >= 0 construct on that GPU (sa_builder.hip); AWRY_BUILD_HOST (-1) host SA-IS;
+// AWRY_BUILD_AUTO (-2): GPU 0 when one is visible and the text is large enough to pay for it
+static void construct(awry_index* ix, const uint8_t* text, uint64_t bwt_len, int alphabet, uint64_t sa_ratio, uint8_t kmer_len,
+                      const uint64_t* seq_starts, const char* const* headers, uint64_t nseq, int build_device) {
+  static const uint64_t zero = 0;
+  if (nseq == 0 || !seq_starts) { seq_starts = &zero; nseq = 1; headers = nullptr; }
+  if (build_device == AWRY_BUILD_AUTO) {
+    const char* e = getenv("AWRY_BUILD");
+    int ndev = 0;
+    if (e && !strcmp(e, "host")) build_device = AWRY_BUILD_HOST;
+    else if (hipGetDeviceCount(&ndev) == hipSuccess && ndev > 0 && bwt_len < (1ull << 32) - 1 && (bwt_len >= (1u << 20) || (e && !strcmp(e, "gpu"))))
+      build_device = 0;
+    else build_device = AWRY_BUILD_HOST;
+  }
+  if (build_device < 0) {
+    build_from_text(ix->host, text, bwt_len, alphabet, sa_ratio, kmer_len, seq_starts, headers, nseq);
+    return;
+  }
+  prepare_build(ix->host, text, bwt_len, alphabet, sa_ratio, kmer_len, seq_starts, headers, nseq);
+  try {
+    gpu_build_index(ix->host, text, bwt_len, build_device, getenv("AWRY_VERBOSE") != nullptr);
+  } catch (const std::bad_alloc&) {
+    throw;
+  } catch (const std::exception& e) {
+    throw HipError(std::string("GPU index construction: ") + e.what());
+  }
+}
+
+int awry_build_from_text_on(const uint8_t* text, uint64_t bwt_len, int alphabet, uint64_t sa_ratio, uint8_t kmer_len,
+                            const uint64_t* seq_starts, const char* const* headers, uint64_t nseq, int build_device,
+                            awry_index_t** out) {
   return guarded([&] {
     require(text && out && bwt_len > 0, "null argument");
     require(alphabet == NUCLEOTIDE || alphabet == AMINO, "bad alphabet id");
-    static const uint64_t zero = 0;
-    if (nseq == 0 || !seq_starts) { seq_starts = &zero; nseq = 1; headers = nullptr; }
+    require(build_device >= AWRY_BUILD_AUTO, "bad build device");
     auto ix = std::make_unique<awry_index>();
-    build_from_text(ix->host, text, bwt_len, alphabet, sa_ratio, kmer_len, seq_starts, headers, nseq);
+    construct(ix.get(), text, bwt_len, alphabet, sa_ratio, kmer_len, seq_starts, headers, nseq, build_device);
     *out = ix.release();
   });
+}
+
+int awry_build_from_text(const uint8_t* text, uint64_t bwt_len, int alphabet, uint64_t sa_ratio, uint8_t kmer_len,
+                         const uint64_t* seq_starts, const char* const* headers, uint64_t nseq, awry_index_t** out) {
+  return awry_build_from_text_on(text, bwt_len, alphabet, sa_ratio, kmer_len, seq_starts, headers, nseq, AWRY_BUILD_AUTO, out);
 }
 
 int awry_build(const awry_build_args_t* args, awry_index_t** out) {
@@ -453,8 +486,8 @@ int awry_build(const awry_build_args_t* args, awry_index_t** out) {
     std::vector<const char*> hdr;
     for (auto& h : sf.headers) hdr.push_back(h.c_str());
     auto ix = std::make_unique<awry_index>();
-    build_from_text(ix->host, sf.text.data(), sf.text.size(), args->alphabet, args->sa_ratio, args->kmer_len,
-                    sf.starts.data(), hdr.data(), sf.starts.size());
+    construct(ix.get(), sf.text.data(), sf.text.size(), args->alphabet, args->sa_ratio, args->kmer_len, sf.starts.data(),
+              hdr.data(), sf.starts.size(), AWRY_BUILD_AUTO);
     *out = ix.release();
   });
 }

@@ -190,6 +190,20 @@ void pack_index(HostIndex& ix, const uint8_t* text, uint64_t bwt_len, const uint
     });
 }
 
+void prepare_build(HostIndex& ix, const uint8_t* text, uint64_t bwt_len, int alphabet, uint64_t sa_ratio,
+                   unsigned kmer_len, const uint64_t* seq_starts, const char* const* headers, uint64_t nseq) {
+  if (bwt_len == 0 || text[bwt_len - 1] != '$') throw std::runtime_error("text must end with '$'");
+  if (alphabet != NUCLEOTIDE && alphabet != AMINO) throw std::runtime_error("bad alphabet id");
+  ix.alphabet = alphabet;
+  ix.sa_ratio = sa_ratio ? sa_ratio : 8;                                     // src/fm_index.rs:122
+  ix.kmer_len = (uint8_t)(kmer_len ? kmer_len : (alphabet == NUCLEOTIDE ? 10 : 4));  // src/kmer_lookup_table.rs:23-24
+  ref_kmer_table_entries(alphabet, ix.kmer_len);                            // range check
+  ix.seq_starts.assign(seq_starts, seq_starts + nseq);
+  ix.headers.clear();
+  for (uint64_t i = 0; i < nseq; i++) ix.headers.emplace_back(headers && headers[i] ? headers[i] : "");
+  ix.ref_kmer_table.clear();
+}
+
 void build_from_text(HostIndex& ix, const uint8_t* text, uint64_t bwt_len, int alphabet, uint64_t sa_ratio,
                      unsigned kmer_len, const uint64_t* seq_starts, const char* const* headers, uint64_t nseq) {
   if (bwt_len == 0 || text[bwt_len - 1] != '$') throw std::runtime_error("text must end with '$'");

@@ -46,9 +46,17 @@ SequenceFile read_sequence_file(const std::string& path, int alphabet);
 void pack_index(HostIndex& ix, const uint8_t* text, uint64_t bwt_len, const uint64_t* sa64,
                 const uint32_t* sa32);
 
+// validates the arguments and fills the metadata fields (alphabet, ratios, records); no suffix array yet
+void prepare_build(HostIndex& ix, const uint8_t* text, uint64_t bwt_len, int alphabet, uint64_t sa_ratio,
+                   unsigned kmer_len, const uint64_t* seq_starts, const char* const* headers, uint64_t nseq);
+
 // text (ending in '$') -> index, host suffix array (sais.hpp)
 void build_from_text(HostIndex& ix, const uint8_t* text, uint64_t bwt_len, int alphabet, uint64_t sa_ratio,
                      unsigned kmer_len, const uint64_t* seq_starts, const char* const* headers, uint64_t nseq);
+
+// same result as the suffix-array + pack_index part of build_from_text, computed on a GPU (sa_builder.hip);
+// ix.alphabet / sa_ratio must be set; needs bwt_len < 2^32 - 1
+void gpu_build_index(HostIndex& ix, const uint8_t* text, uint64_t bwt_len, int device, bool verbose);
 
 // reference block layout (planes then milestones, src/fm_index_file.rs:58-67) <-> device layout
 void block_to_reference(const HostIndex& ix, uint64_t b, uint64_t* out /* 20 or 44 words */);

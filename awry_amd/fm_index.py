@@ -12,6 +12,7 @@ import numpy as np
 from . import _lib
 
 NUCLEOTIDE, AMINO = 0, 1
+BUILD_HOST, BUILD_AUTO = -1, -2
 
 
 class SymbolAlphabet:  # src/alphabet.rs:28-31
@@ -109,15 +110,17 @@ class FmIndex:
         return cls(h.value)
 
     @classmethod
-    def from_text(cls, text, alphabet=NUCLEOTIDE, sa_ratio=8, kmer_len=0, seq_starts=(0,), headers=("seq0",)) -> "FmIndex":
-        """index an in-memory text that already follows the reference's text model (ends in '$')"""
+    def from_text(cls, text, alphabet=NUCLEOTIDE, sa_ratio=8, kmer_len=0, seq_starts=(0,), headers=("seq0",),
+                  build_device=BUILD_AUTO) -> "FmIndex":
+        """index an in-memory text that already follows the reference's text model (ends in '$');
+        build_device: GPU id, BUILD_HOST (host SA-IS) or BUILD_AUTO"""
         L = _lib.load_library()
         t = np.frombuffer(_as_bytes(text), dtype=np.uint8) if not isinstance(text, np.ndarray) else np.ascontiguousarray(text, np.uint8)
         st = np.ascontiguousarray(list(seq_starts), dtype=np.uint64)
         hd = (C.c_char_p * len(headers))(*[h.encode() for h in headers])
         h = C.c_void_p()
-        _check(L.awry_build_from_text(t.ctypes.data, len(t), alphabet, sa_ratio, kmer_len, st.ctypes.data_as(_u64p), hd,
-                                      len(headers), C.byref(h)))
+        _check(L.awry_build_from_text_on(t.ctypes.data, len(t), alphabet, sa_ratio, kmer_len, st.ctypes.data_as(_u64p), hd,
+                                         len(headers), build_device, C.byref(h)))
         return cls(h.value)
 
     @classmethod

@@ -58,6 +58,14 @@ int awry_build(const awry_build_args_t *args, awry_index_t **out);
  * trailing '$', src/fm_index.rs:148-153,220-223); seq_starts/headers describe the records */
 int awry_build_from_text(const uint8_t *text, uint64_t bwt_len, int alphabet, uint64_t sa_ratio, uint8_t kmer_len,
                          const uint64_t *seq_starts, const char *const *headers, uint64_t nseq, awry_index_t **out);
+/* same with an explicit choice of where the suffix array and the BWT are constructed: a device id >= 0
+ * (GPU prefix doubling + streaming pack kernels), AWRY_BUILD_HOST (host SA-IS) or AWRY_BUILD_AUTO (what
+ * awry_build / awry_build_from_text use: GPU 0 if visible and bwt_len >= 2^20, else host; env AWRY_BUILD=host|gpu
+ * overrides).  All choices produce bit-identical indexes. */
+enum { AWRY_BUILD_HOST = -1, AWRY_BUILD_AUTO = -2 };
+int awry_build_from_text_on(const uint8_t *text, uint64_t bwt_len, int alphabet, uint64_t sa_ratio, uint8_t kmer_len,
+                            const uint64_t *seq_starts, const char *const *headers, uint64_t nseq, int build_device,
+                            awry_index_t **out);
 /* FmIndex::load / FmIndex::save, src/fm_index_file.rs:132,42 (.awry v1, byte-compatible) */
 int awry_load(const char *path, awry_index_t **out);
 int awry_save(awry_index_t *idx, const char *path); /* needs a device: fills the k-mer table on the GPU */

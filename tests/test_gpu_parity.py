@@ -188,3 +188,28 @@ def test_medium_scale_properties():
     assert np.array_equal(win, q2d[qi])
     assert len(np.unique(gpos + qi.astype(np.uint64) * np.uint64(n + 1))) == len(gpos)
     assert (pos[:, 0] == 0).all() and np.array_equal(pos[:, 1], gpos)
+
+
+@pytest.mark.parametrize("alphabet,n,recs,nfrac,ratio,seed", [
+    (0, 1, 1, 0.0, 8, 1), (0, 2, 1, 0.0, 8, 2), (0, 5, 1, 0.0, 1, 3), (0, 300, 2, 0.0, 8, 4), (0, 70000, 3, 0.2, 8, 5),
+    (1, 50000, 30, 0.02, 5, 6), (0, 1_000_000, 4, 0.07, 8, 7), (1, 400_000, 900, 0.0, 8, 8), (0, 3_000_001, 1, 0.3, 16, 9)])
+def test_gpu_construction_is_bit_identical_to_host(alphabet, n, recs, nfrac, ratio, seed):
+    """FmIndex::new on the GPU (prefix-doubling SA + streaming pack kernels, sa_builder.hip) == host SA-IS + pack_index"""
+    text, st, hd = synth.make_text(n, alphabet, seed, recs, nfrac)
+    host = FmIndex.from_text(text, alphabet, ratio, 0, st, hd, build_device=-1)
+    gpu = FmIndex.from_text(text, alphabet, ratio, 0, st, hd, build_device=0)
+    assert gpu.bwt_len() == host.bwt_len() and gpu.sentinel_row() == host.sentinel_row()
+    assert np.array_equal(gpu.prefix_sums(), host.prefix_sums())
+    assert np.array_equal(gpu.sa_words(), host.sa_words())
+    assert np.array_equal(gpu.device_block_words(), host.device_block_words())
+    assert gpu.sequences() == host.sequences()
+
+
+def test_gpu_construction_degenerate_texts():
+    for t in (b"$", b"A$", b"A" * 5000 + b"$", b"N" * 70000 + b"$", b"AC" * 40000 + b"$", b"ACGTN" * 9000 + b"$",
+              (b"GATTACA" * 3000 + b"N") * 7 + b"$", b"T" * 300 + b"G" * 300 + b"C" * 300 + b"A" * 300 + b"$"):
+        host = FmIndex.from_text(t, 0, 4, 0, build_device=-1)
+        gpu = FmIndex.from_text(t, 0, 4, 0, build_device=0)
+        assert np.array_equal(gpu.device_block_words(), host.device_block_words()), t[:20]
+        assert np.array_equal(gpu.sa_words(), host.sa_words()) and gpu.sentinel_row() == host.sentinel_row()
+        assert np.array_equal(gpu.prefix_sums(), host.prefix_sums())

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -83,6 +84,8 @@ struct Replica {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   DevBuf<uint64_t> blocks, sa_words, seq_starts;
   DevBuf<SeedEntry> seed;
+  DevBuf<unsigned long long> chunk_counters;  // ring of work-queue heads, one per in-flight count launch
+  std::atomic<unsigned> launch_seq{0};
   int seed_k = 0;
   int num_cus = 256;
   DevIndex dev{};
@@ -92,7 +95,7 @@ struct Replica {
       if (stream) (void)hipStreamDestroy(stream);
       if (ev0) (void)hipEventDestroy(ev0);
       if (ev1) (void)hipEventDestroy(ev1);
-      blocks.reset(); sa_words.reset(); seq_starts.reset(); seed.reset();
+      blocks.reset(); sa_words.reset(); seq_starts.reset(); seed.reset(); chunk_counters.reset();
     }
   }
 };
@@ -129,8 +132,14 @@ bool narrow(const HostIndex& h) { return h.bwt_len < (1ull << 32) - 512; }
 int default_seed_k(const HostIndex& h) {
   if (h.alphabet != NUCLEOTIDE || !narrow(h)) return 0;
   if (const char* e = getenv("AWRY_SEED_K")) return std::max(0, std::min(16, atoi(e)));
-  int k = (int)std::floor(std::log((double)h.bwt_len) / std::log(4.0));
-  return std::max(1, std::min(k, 14));
+  // about one table entry per suffix: 4^k ~ bwt_len (GRCh38: k = 16, 34 GB of the 288 GB HBM; chr1: 14; E. coli: 11).
+  // A random k-mer's range is then ~1 row, so a query costs one probe plus ~1 step instead of ~16 steps.
+  int k = (int)std::lround(std::log((double)h.bwt_len) / std::log(4.0));
+  k = std::max(1, std::min(k, 16));
+  size_t free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
+    while (k > 1 && (5ull << (2 * k)) * 2 > free_b / 2) k--;  // table + its build scratch within half of the free HBM
+  return k;
 }
 
 // level-by-level seed table on the replica's device (see seed_extend_kernel)
@@ -179,6 +188,7 @@ std::unique_ptr<Replica> make_replica(awry_index* ix, int device) {
   r->blocks.alloc(h.blocks.size());
   r->sa_words.alloc(h.sa_words.size() + 1);  // +1: the straddle read of the last sample never leaves the buffer
   r->seq_starts.alloc(std::max<size_t>(1, h.seq_starts.size()));
+  r->chunk_counters.alloc(64);
   HIP_CHECK(hipMemcpy(r->blocks.p, h.blocks.data(), h.blocks.size() * 8, hipMemcpyHostToDevice));
   HIP_CHECK(hipMemset(r->sa_words.p, 0, (h.sa_words.size() + 1) * 8));
   if (!h.sa_words.empty()) HIP_CHECK(hipMemcpy(r->sa_words.p, h.sa_words.data(), h.sa_words.size() * 8, hipMemcpyHostToDevice));
@@ -245,6 +255,23 @@ void launch_count_nt2(Replica& r, const uint64_t* d_words, uint64_t n, int L, ui
   if (n == 0) return;
   const bool seeded = use_seed && r.seed_k > 0 && r.seed_k <= L;
   const dim3 g(grid_for(r, n * 4, 256)), b(256);
+  // AWRY_COUNT_KERNEL=chunk selects the LDS-staged variant (count_nt2_chunk_kernel).  Measured on MI355X it is
+  // equal at seed k=14 and 23% slower at k=16 (GRCh38-scale): the strided kernel's query words already arrive
+  // as L2 hits, so staging only removes the partial-line result writes and pays chunk drain + refill for it.
+  static const bool use_chunk = getenv("AWRY_COUNT_KERNEL") && !strcmp(getenv("AWRY_COUNT_KERNEL"), "chunk");
+  if (use_chunk) {
+    unsigned long long* ctr = r.chunk_counters.p + (r.launch_seq.fetch_add(1) % 64u);
+    HIP_CHECK(hipMemsetAsync(ctr, 0, 8, s));
+    if (d_tally) {
+      if (seeded) hipLaunchKernelGGL((count_nt2_chunk_kernel<true, true>), g, b, 0, s, r.dev, d_words, n, L, d_counts, ctr, d_tally);
+      else hipLaunchKernelGGL((count_nt2_chunk_kernel<false, true>), g, b, 0, s, r.dev, d_words, n, L, d_counts, ctr, d_tally);
+    } else {
+      if (seeded) hipLaunchKernelGGL((count_nt2_chunk_kernel<true, false>), g, b, 0, s, r.dev, d_words, n, L, d_counts, ctr, d_tally);
+      else hipLaunchKernelGGL((count_nt2_chunk_kernel<false, false>), g, b, 0, s, r.dev, d_words, n, L, d_counts, ctr, d_tally);
+    }
+    HIP_CHECK(hipGetLastError());
+    return;
+  }
   if (d_tally) {
     if (seeded) hipLaunchKernelGGL((count_nt2_quad_kernel<true, true>), g, b, 0, s, r.dev, d_words, n, L, d_counts, d_tally);
     else hipLaunchKernelGGL((count_nt2_quad_kernel<false, true>), g, b, 0, s, r.dev, d_words, n, L, d_counts, d_tally);

@@ -430,6 +430,96 @@ __global__ __launch_bounds__(256) void count_nt2_quad_kernel(DevIndex ix, const 
   }
 }
 
+// v2 of the hot kernel: the query and result streams are staged through LDS in wave-private chunks so that
+// both move as whole 128-B lines (v1 fetched one line per 8-B query word and wrote one partial line per
+// 8-B result: 2 of its ~4 line requests per query).  A wave grabs a chunk of CHUNK consecutive queries with
+// one atomic, loads it coalesced into LDS, hands the queries out to its 16 quads on demand (ballot + prefix
+// popcount), stores each count over the query word it came from, and writes the chunk back coalesced.
+constexpr int NT2_CHUNK = 256;  // queries per wave chunk: 2 KB of LDS per wave, 8 KB per 256-thread block
+
+template <bool USE_SEED, bool TALLY>
+__global__ __launch_bounds__(256) void count_nt2_chunk_kernel(DevIndex ix, const uint64_t* __restrict__ queries, uint64_t n, int L,
+                                                              uint64_t* __restrict__ counts, unsigned long long* __restrict__ chunk_counter,
+                                                              unsigned long long* __restrict__ tally) {
+  __shared__ uint64_t lds_all[4 * NT2_CHUNK];
+  const int lane = threadIdx.x & 63, l = lane & 3;
+  volatile uint64_t* lds = lds_all + (threadIdx.x >> 6) * NT2_CHUNK;  // wave-private; volatile keeps the cross-lane order
+  const uint64_t* __restrict__ blocks = ix.blocks;
+  const SeedEntry* __restrict__ seed = ix.seed;
+  const int k = USE_SEED ? ix.seed_k : 1;
+  const uint32_t cA = (uint32_t)ix.prefix_sums[1], cC = (uint32_t)ix.prefix_sums[2], cG = (uint32_t)ix.prefix_sums[3],
+                 cN = (uint32_t)ix.prefix_sums[4], cT = (uint32_t)ix.prefix_sums[5], cEnd = (uint32_t)ix.prefix_sums[6];
+  const uint64_t nchunks = (n + NT2_CHUNK - 1) / NT2_CHUNK;
+  const uint64_t quad_lt = (1ull << (lane & ~3)) - 1;  // leader lanes of the quads before this one
+  uint32_t t_probe = 0, t_step = 0, t_blk = 0;
+
+  for (;;) {
+    unsigned long long c = 0;
+    if (lane == 0) c = atomicAdd(chunk_counter, 1ull);
+    c = __shfl(c, 0, 64);
+    if (c >= nchunks) break;
+    const uint64_t base = c * NT2_CHUNK;
+    const int cn = (int)(n - base < (uint64_t)NT2_CHUNK ? n - base : (uint64_t)NT2_CHUNK);
+#pragma unroll
+    for (int j = 0; j < NT2_CHUNK / 64; j++) {
+      const int s = j * 64 + lane;
+      lds[s] = s < cn ? queries[base + s] : 0ull;
+    }
+    int cursor = 0;  // wave-uniform: next unassigned slot
+    bool have = false, fresh = true;
+    int slot = 0, i = 0;
+    uint64_t w = 0;
+    uint32_t sp = 1, ep = 0;
+    for (;;) {
+      // hand out queries to idle quads, in slot order
+      const uint64_t needy = __ballot(!have && l == 0);
+      if (!have) {
+        const int idx = cursor + (int)__popcll(needy & quad_lt);
+        if (idx < cn) { have = true; fresh = true; slot = idx; w = lds[idx]; }
+      }
+      cursor += (int)__popcll(needy);
+      if (!__any(have)) break;
+      if (have) {
+        if (fresh) {
+          if (USE_SEED) {
+            const uint32_t sidx = (uint32_t)((w >> (2 * (L - k))) & ((1ull << (2 * k)) - 1));
+            const SeedEntry e = seed[sidx];
+            sp = e.cnt ? e.sp : 1u;
+            ep = e.cnt ? e.sp + e.cnt - 1u : 0u;
+            if (TALLY) t_probe++;
+          } else {
+            const uint32_t ch = (uint32_t)(w >> (2 * (L - 1))) & 3u;  // SearchRange::new(last symbol)
+            sp = ch == 0 ? cA : (ch == 1 ? cC : (ch == 2 ? cG : cT));
+            ep = (ch == 0 ? cC : (ch == 1 ? cG : (ch == 2 ? cN : cEnd))) - 1;
+          }
+          i = L - k;
+          fresh = false;
+        } else {
+          i--;
+          const uint32_t ch = (uint32_t)(w >> (2 * i)) & 3u;
+          const uint32_t cl = ch == 0 ? cA : (ch == 1 ? cC : (ch == 2 ? cG : cT));
+          if (TALLY) { t_step++; t_blk += ((sp - 1) >> 8) == (ep >> 8) ? 1u : 2u; }
+          quad_step(blocks, cl, sp, ep, ch, l);
+        }
+        if (sp > ep || i == 0) {
+          if (l == 0) lds[slot] = sp > ep ? 0ull : (uint64_t)(ep - sp) + 1ull;  // the count replaces the query word
+          have = false;
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < NT2_CHUNK / 64; j++) {
+      const int s = j * 64 + lane;
+      if (s < cn) counts[base + s] = lds[s];
+    }
+  }
+  if (TALLY && l == 0) {
+    atomicAdd(&tally[0], (unsigned long long)t_probe);
+    atomicAdd(&tally[1], (unsigned long long)t_step);
+    atomicAdd(&tally[2], (unsigned long long)t_blk);
+  }
+}
+
 // Seed table, level by level: entry o of level j+1 (window letters w_0..w_j, index = sum w_t 4^t with the
 // LAST query symbol most significant) is one step of its parent o >> 2 with letter o & 3.
 __global__ __launch_bounds__(256) void seed_level1_kernel(DevIndex ix, SeedEntry* __restrict__ out) {

@@ -49,13 +49,14 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default=os.environ.get("AWRY_BENCH_WORKLOAD", "chr1"), choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default=os.environ.get("AWRY_BENCH_WORKLOAD", "grch38"), choices=sorted(WORKLOADS))
     ap.add_argument("--text-len", type=int, default=0, help="override the workload's text length")
     ap.add_argument("--queries", type=int, default=10_000_000, help="queries per GPU per step")
     ap.add_argument("--qlen", type=int, default=31)
     ap.add_argument("--seed-k", type=int, default=-1, help="device seed-table k (-1 = library default, 0 = off)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline duration (0 = skip)")
     ap.add_argument("--no-variants", action="store_true")
+    ap.add_argument("--sweep-seed-k", default="", help="comma list of seed k to time on rank 0 before the run (stderr)")
     args = ap.parse_args()
 
     import torch
@@ -110,6 +111,21 @@ def main():
 
     def step(i, seeded=True):
         ix.dev_count_nt2(batches[i % n_batches].data_ptr(), nq, L, counts.data_ptr(), seeded, stream, 0)
+
+    if args.sweep_seed_k and rank == 0:
+        for k in [int(x) for x in args.sweep_seed_k.split(",")]:
+            ix.set_seed_kmer_len(k)
+            for i in range(2):
+                step(i)
+            torch.cuda.synchronize()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for i in range(5):
+                step(i)
+            b.record()
+            torch.cuda.synchronize()
+            log("sweep seed k=%d: %.3f ms/launch, %.2f G queries/s" % (k, a.elapsed_time(b) / 5, nq / (a.elapsed_time(b) / 5) / 1e6))
+        ix.set_seed_kmer_len(args.seed_k)
 
     for i in range(W):
         step(i)
@@ -225,25 +241,26 @@ def main():
             os.remove(path)
             log("oracle index via .awry round trip: %.1fs" % (time.time() - ts))
             cores = os.cpu_count() or 1
-            w0 = batches[W % n_batches][:4_000_000].cpu().numpy().view(np.uint64)
-            probe_n = 100_000
-            qb, qo = synth.fixed_to_csr(unpack_nt2(w0[:probe_n], L))
+            sample = min(nq, 10_000_000)
+            w0 = batches[W % n_batches][:sample].cpu().numpy().view(np.uint64)
+            qb, qo = synth.fixed_to_csr(unpack_nt2(w0, L))
+            probe_n = min(sample, 500_000)
             tp = time.perf_counter()
-            oi.parallel_count(qb, qo, cores)
+            oi.parallel_count(qb[:probe_n * L], qo[:probe_n + 1], cores)
             rate = probe_n / (time.perf_counter() - tp)
-            sample = int(max(probe_n, min(len(w0), rate * args.cpu_seconds)))
-            qb, qo = synth.fixed_to_csr(unpack_nt2(w0[:sample], L))
+            passes = int(max(1, min(200, round(rate * args.cpu_seconds / sample))))
             tp = time.perf_counter()
-            ocounts, otally = oi.parallel_count(qb, qo, cores)
-            dt = time.perf_counter() - tp
+            for _ in range(passes):  # the sample touches far more index bytes than the host caches hold
+                ocounts, otally = oi.parallel_count(qb, qo, cores)
+            dt = (time.perf_counter() - tp) / passes
             # parity of the timed GPU path against the oracle on the same sample
             ix.dev_count_nt2(batches[W % n_batches].data_ptr(), nq, L, counts.data_ptr(), True, stream, 0)
             torch.cuda.synchronize()
             gcounts = counts[:sample].cpu().numpy().view(np.uint64)
             parity = bool(np.array_equal(gcounts, ocounts))
             result["cpu_baseline"] = {"value": sample / dt, "unit": "queries/s", "cores": cores, "kind": "port",
-                                      "sample": "first %d queries of timed batch 0 (same index via .awry v1 round trip), "
-                                                "reference step schedule, %d threads, %.1f s" % (sample, cores, dt),
+                                      "sample": "first %d queries of timed batch 0 x %d passes (same index via .awry v1 round trip), "
+                                                "reference step schedule, %d threads, %.1f s total" % (sample, passes, cores, dt * passes),
                                       "steps_per_query": otally["steps"] / sample,
                                       "block_reads_per_query": otally["block_reads"] / sample,
                                       "gpu_matches_oracle_on_sample": parity}

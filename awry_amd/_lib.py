@@ -106,7 +106,10 @@ def load_library():
     sig("awry_dev_count_ascii", i32, vp, i32, vp, vp, u64, vp, vp, vp, vp)
     sig("awry_dev_scan_scratch_bytes", u64, u64)
     sig("awry_dev_scan_counts", i32, vp, i32, vp, u64, vp, vp, vp)
-    sig("awry_dev_locate", i32, vp, i32, vp, vp, u64, u64, vp, vp, vp)
+    sig("awry_dev_locate", i32, vp, i32, vp, i32, vp, u64, u64, vp, vp, vp)
+    sig("awry_dev_count_nt2_long", i32, vp, i32, vp, u64, i32, vp, vp, i32, vp)
+    sig("awry_set_locate_sa_ratio", i32, vp, i32)
+    sig("awry_locate_sa_ratio", i32, vp)
     sig("awry_dev_malloc", i32, vp, i32, u64, vpp)
     sig("awry_dev_free", i32, vp, i32, vp)
     sig("awry_dev_memcpy_h2d", i32, vp, i32, vp, vp, u64)

@@ -84,7 +84,9 @@ struct Replica {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   DevBuf<uint64_t> blocks, sa_words, seq_starts;
   DevBuf<SeedEntry> seed;
-  DevBuf<unsigned long long> chunk_counters;  // ring of work-queue heads, one per in-flight count launch
+  DevBuf<unsigned long long> chunk_counters;  // ring of work-queue heads, one per in-flight count / locate launch
+  DevBuf<uint32_t> dense_sa;                  // SA[j * dense_ratio] as u32 (device-only accelerator for locate)
+  uint32_t dense_ratio = 0;                   // 0 = use the file's bit-packed samples
   std::atomic<unsigned> launch_seq{0};
   int seed_k = 0;
   int num_cus = 256;
@@ -95,7 +97,7 @@ struct Replica {
       if (stream) (void)hipStreamDestroy(stream);
       if (ev0) (void)hipEventDestroy(ev0);
       if (ev1) (void)hipEventDestroy(ev1);
-      blocks.reset(); sa_words.reset(); seq_starts.reset(); seed.reset(); chunk_counters.reset();
+      blocks.reset(); sa_words.reset(); seq_starts.reset(); seed.reset(); chunk_counters.reset(); dense_sa.reset();
     }
   }
 };
@@ -105,7 +107,8 @@ struct Replica {
 struct awry_index {
   HostIndex host;
   std::vector<std::unique_ptr<Replica>> reps;
-  int seed_k_request = -1;  // -1 = default policy
+  int seed_k_request = -1;      // -1 = default policy
+  int dense_ratio_request = 0;  // 0 = locate walks to the file's SA samples
 };
 
 namespace {
@@ -170,6 +173,8 @@ void build_seed(awry_index* ix, Replica& r, int k) {
   r.dev.seed_k = k;
 }
 
+void build_dense_sa(awry_index* ix, Replica& r, int ratio);
+
 std::unique_ptr<Replica> make_replica(awry_index* ix, int device) {
   int ndev = 0;
   hipError_t e = hipGetDeviceCount(&ndev);
@@ -209,6 +214,7 @@ std::unique_ptr<Replica> make_replica(awry_index* ix, int device) {
   d.alphabet = h.alphabet;
   d.seed_k = 0;
   build_seed(ix, *r, ix->seed_k_request < 0 ? default_seed_k(h) : ix->seed_k_request);
+  build_dense_sa(ix, *r, ix->dense_ratio_request);
   return r;
 }
 
@@ -236,14 +242,67 @@ void launch_scan(Replica& r, const uint64_t* d_counts, uint64_t n, uint64_t* d_h
   HIP_CHECK(hipGetLastError());
 }
 
-void launch_locate(Replica& r, const uint64_t* d_ranges, const uint64_t* d_hit_off, uint64_t n, uint64_t total,
+unsigned long long* next_counter(Replica& r, hipStream_t s) {
+  unsigned long long* ctr = r.chunk_counters.p + (r.launch_seq.fetch_add(1) % 64u);
+  HIP_CHECK(hipMemsetAsync(ctr, 0, 8, s));
+  return ctr;
+}
+
+// d_range_start[q * rs_stride] = first BWT row of query q's range
+void launch_locate(Replica& r, const uint64_t* d_range_start, int rs_stride, const uint64_t* d_hit_off, uint64_t n, uint64_t total,
                    uint64_t* d_gpos, uint64_t* d_pos, hipStream_t s) {
   if (total == 0) return;
-  const dim3 g(grid_for(r, total, 256)), b(256);
+  static const bool scalar = getenv("AWRY_LOCATE_KERNEL") && !strcmp(getenv("AWRY_LOCATE_KERNEL"), "scalar");
+  if (scalar && rs_stride == 2) {  // round-1 baseline kernel: one hit per lane, global binary search, file samples only
+    const dim3 g(grid_for(r, total, 256)), b(256);
+    if (r.dev.alphabet == NUCLEOTIDE)
+      hipLaunchKernelGGL(locate_scalar_kernel<NUCLEOTIDE>, g, b, 0, s, r.dev, d_range_start, d_hit_off, n, total, d_gpos, d_pos);
+    else
+      hipLaunchKernelGGL(locate_scalar_kernel<AMINO>, g, b, 0, s, r.dev, d_range_start, d_hit_off, n, total, d_gpos, d_pos);
+    HIP_CHECK(hipGetLastError());
+    return;
+  }
+  unsigned long long* ctr = next_counter(r, s);
+  const uint64_t tiles = (total + LOC_TILE - 1) / LOC_TILE;
+  const dim3 g((unsigned)std::min<uint64_t>(tiles, (uint64_t)r.num_cus * 8)), b(256);
+  const uint32_t* dense = r.dense_ratio ? r.dense_sa.p : nullptr;
   if (r.dev.alphabet == NUCLEOTIDE)
-    hipLaunchKernelGGL(locate_scalar_kernel<NUCLEOTIDE>, g, b, 0, s, r.dev, d_ranges, d_hit_off, n, total, d_gpos, d_pos);
+    hipLaunchKernelGGL(locate_tile_kernel<NUCLEOTIDE>, g, b, 0, s, r.dev, d_range_start, rs_stride, d_hit_off, n, total, dense, r.dense_ratio,
+                       d_gpos, d_pos, ctr);
   else
-    hipLaunchKernelGGL(locate_scalar_kernel<AMINO>, g, b, 0, s, r.dev, d_ranges, d_hit_off, n, total, d_gpos, d_pos);
+    hipLaunchKernelGGL(locate_tile_kernel<AMINO>, g, b, 0, s, r.dev, d_range_start, rs_stride, d_hit_off, n, total, dense, r.dense_ratio,
+                       d_gpos, d_pos, ctr);
+  HIP_CHECK(hipGetLastError());
+}
+
+// dense device SA for locate: ratio 0 = off (walk to the file's samples), r >= 1 = keep SA[j r] for every j as u32
+void build_dense_sa(awry_index* ix, Replica& r, int ratio) {
+  r.dense_sa.reset();
+  r.dense_ratio = 0;
+  if (ratio <= 0) return;
+  require(ix->host.bwt_len < (1ull << 32), "a dense device SA needs bwt_len < 2^32");
+  if ((uint64_t)ratio >= ix->host.sa_ratio && ix->host.sa_ratio % (uint64_t)ratio == 0 && (uint64_t)ratio == ix->host.sa_ratio) return;
+  const uint64_t nentries = (ix->host.bwt_len + ratio - 1) / ratio;
+  DevBuf<uint32_t> d(nentries);
+  const dim3 g(grid_for(r, nentries, 256)), b(256);
+  if (r.dev.alphabet == NUCLEOTIDE) hipLaunchKernelGGL(densify_sa_kernel<NUCLEOTIDE>, g, b, 0, r.stream, r.dev, (uint32_t)ratio, nentries, d.p);
+  else hipLaunchKernelGGL(densify_sa_kernel<AMINO>, g, b, 0, r.stream, r.dev, (uint32_t)ratio, nentries, d.p);
+  HIP_CHECK(hipGetLastError());
+  HIP_CHECK(hipStreamSynchronize(r.stream));
+  r.dense_sa = std::move(d);
+  r.dense_ratio = (uint32_t)ratio;
+}
+
+void launch_count_nt2_long(Replica& r, const uint64_t* d_words, uint64_t n, int L, uint64_t* d_counts, uint64_t* d_range_start,
+                           bool use_seed, hipStream_t s) {
+  require(r.dev.alphabet == NUCLEOTIDE, "packed 2-bit queries need a nucleotide index");
+  require(r.dev.bwt_len < (1ull << 32) - 512, "the quad kernel needs bwt_len < 2^32");
+  require(L >= 1 && L <= 1 << 20, "packed read length out of range");
+  if (n == 0) return;
+  const bool seeded = use_seed && r.seed_k > 0 && r.seed_k <= L;
+  const dim3 g(grid_for(r, n * 4, 256)), b(256);
+  if (seeded) hipLaunchKernelGGL(count_nt2_long_quad_kernel<true>, g, b, 0, s, r.dev, d_words, n, L, d_counts, d_range_start);
+  else hipLaunchKernelGGL(count_nt2_long_quad_kernel<false>, g, b, 0, s, r.dev, d_words, n, L, d_counts, d_range_start);
   HIP_CHECK(hipGetLastError());
 }
 
@@ -260,8 +319,7 @@ void launch_count_nt2(Replica& r, const uint64_t* d_words, uint64_t n, int L, ui
   // as L2 hits, so staging only removes the partial-line result writes and pays chunk drain + refill for it.
   static const bool use_chunk = getenv("AWRY_COUNT_KERNEL") && !strcmp(getenv("AWRY_COUNT_KERNEL"), "chunk");
   if (use_chunk) {
-    unsigned long long* ctr = r.chunk_counters.p + (r.launch_seq.fetch_add(1) % 64u);
-    HIP_CHECK(hipMemsetAsync(ctr, 0, 8, s));
+    unsigned long long* ctr = next_counter(r, s);
     if (d_tally) {
       if (seeded) hipLaunchKernelGGL((count_nt2_chunk_kernel<true, true>), g, b, 0, s, r.dev, d_words, n, L, d_counts, ctr, d_tally);
       else hipLaunchKernelGGL((count_nt2_chunk_kernel<false, true>), g, b, 0, s, r.dev, d_words, n, L, d_counts, ctr, d_tally);
@@ -378,7 +436,7 @@ void locate_shard(Replica& r, const uint8_t* qbytes, const uint64_t* qoff, Shard
     if (total == 0) continue;
     if (d_gpos.n < total) d_gpos.alloc(total);
     if (d_pos.n < 2 * total) d_pos.alloc(2 * total);
-    launch_locate(r, cb.ranges.p, hit_off.p, n, total, d_gpos.p, d_pos.p, r.stream);
+    launch_locate(r, cb.ranges.p, 2, hit_off.p, n, total, d_gpos.p, d_pos.p, r.stream);
     const size_t at = out.pos.size();
     out.pos.resize(at + total);
     HIP_CHECK(hipMemcpyAsync(out.pos.data() + at, d_pos.p, total * 16, hipMemcpyDeviceToHost, r.stream));
@@ -726,7 +784,7 @@ uint8_t awry_symbol_index(int alphabet, uint8_t ascii) { return (uint8_t)index_o
 int awry_dev_pack_nt2(awry_index_t* idx, int slot, const void* d_ascii, uint64_t n, int L, void* d_words, void* d_bad, void* stream) {
   return guarded([&] {
     Replica& r = replica(idx, slot);
-    require(L >= 1 && L <= 32, "packed k-mer length must be in 1..32");
+    require(L >= 1 && L <= (1 << 20), "packed read length out of range");
     require(d_ascii && d_words && d_bad, "null device pointer");
     if (n == 0) return;
     hipLaunchKernelGGL(pack_nt2_kernel, dim3(grid_for(r, n, 256)), dim3(256), 0, (hipStream_t)stream,
@@ -753,6 +811,28 @@ int awry_dev_count_nt2_tally(awry_index_t* idx, int slot, const void* d_words, u
   });
 }
 
+int awry_dev_count_nt2_long(awry_index_t* idx, int slot, const void* d_words, uint64_t n, int L, void* d_counts, void* d_range_start,
+                            int use_seed, void* stream) {
+  return guarded([&] {
+    Replica& r = replica(idx, slot);
+    require((d_words && d_counts) || n == 0, "null device pointer");
+    launch_count_nt2_long(r, (const uint64_t*)d_words, n, L, (uint64_t*)d_counts, (uint64_t*)d_range_start, use_seed != 0, (hipStream_t)stream);
+  });
+}
+
+int awry_set_locate_sa_ratio(awry_index_t* idx, int ratio) {
+  return guarded([&] {
+    require(idx != nullptr, "null index");
+    require(ratio >= 0 && ratio <= 1024, "dense SA ratio must be in 0..1024");
+    idx->dense_ratio_request = ratio;
+    for (size_t s = 0; s < idx->reps.size(); s++) build_dense_sa(idx, replica(idx, (int)s), ratio);
+  });
+}
+int awry_locate_sa_ratio(const awry_index_t* idx) {
+  if (!idx || idx->reps.empty()) return 0;
+  return idx->reps[0]->dense_ratio ? (int)idx->reps[0]->dense_ratio : (int)idx->host.sa_ratio;
+}
+
 int awry_dev_count_ascii(awry_index_t* idx, int slot, const void* d_qbytes, const void* d_qoff, uint64_t n, void* d_counts,
                          void* d_ranges, void* d_status, void* stream) {
   return guarded([&] {
@@ -773,13 +853,14 @@ int awry_dev_scan_counts(awry_index_t* idx, int slot, const void* d_counts, uint
   });
 }
 
-int awry_dev_locate(awry_index_t* idx, int slot, const void* d_ranges, const void* d_hit_off, uint64_t n, uint64_t total,
-                    void* d_global_pos, void* d_pos, void* stream) {
+int awry_dev_locate(awry_index_t* idx, int slot, const void* d_ranges, int range_stride, const void* d_hit_off, uint64_t n,
+                    uint64_t total, void* d_global_pos, void* d_pos, void* stream) {
   return guarded([&] {
     Replica& r = replica(idx, slot);
     require((d_ranges && d_hit_off && d_global_pos) || total == 0, "null device pointer");
-    launch_locate(r, (const uint64_t*)d_ranges, (const uint64_t*)d_hit_off, n, total, (uint64_t*)d_global_pos, (uint64_t*)d_pos,
-                  (hipStream_t)stream);
+    require(range_stride == 1 || range_stride == 2, "range_stride must be 1 (starts) or 2 ((start,end) pairs)");
+    launch_locate(r, (const uint64_t*)d_ranges, range_stride, (const uint64_t*)d_hit_off, n, total, (uint64_t*)d_global_pos,
+                  (uint64_t*)d_pos, (hipStream_t)stream);
   });
 }
 

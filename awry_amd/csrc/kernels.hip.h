@@ -556,6 +556,7 @@ __global__ __launch_bounds__(256) void seed_extend_kernel(DevIndex ix, const See
 __global__ __launch_bounds__(256) void pack_nt2_kernel(const uint8_t* __restrict__ ascii, uint64_t n, int L,
                                                        uint64_t* __restrict__ words, unsigned long long* __restrict__ bad) {
   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  const int W = (L + 31) / 32;  // words per query: letter j in word j / 32, bits 2 (j % 32)
   for (uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += stride) {
     const uint8_t* p = ascii + q * (uint64_t)L;
     uint64_t w = 0;
@@ -564,10 +565,166 @@ __global__ __launch_bounds__(256) void pack_nt2_kernel(const uint8_t* __restrict
       uint8_t a = p[j] & 0xDF;  // upper-case
       uint32_t c = a == 'A' ? 0u : (a == 'C' ? 1u : (a == 'G' ? 2u : (a == 'T' ? 3u : 4u)));
       ok = ok && c < 4u && p[j] < 0x80;
-      w |= (uint64_t)(c & 3u) << (2 * j);
+      w |= (uint64_t)(c & 3u) << (2 * (j & 31));
+      if ((j & 31) == 31 || j == L - 1) { words[q * W + (j >> 5)] = w; w = 0; }
     }
-    words[q] = w;
     if (!ok) atomicAdd(bad, 1ull);
+  }
+}
+
+// Packed reads of any length (W = ceil(L/32) words per query, same letter order as above) with the final range
+// written out for locate: the quad design of count_nt2_quad_kernel, the current word re-read every 32 letters.
+template <bool USE_SEED>
+__global__ __launch_bounds__(256) void count_nt2_long_quad_kernel(DevIndex ix, const uint64_t* __restrict__ queries, uint64_t n, int L,
+                                                                  uint64_t* __restrict__ counts, uint64_t* __restrict__ range_start) {
+  const int l = threadIdx.x & 3;
+  const uint64_t nquads = ((uint64_t)gridDim.x * blockDim.x) >> 2;
+  uint64_t q = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 2;
+  const uint64_t* __restrict__ blocks = ix.blocks;
+  const SeedEntry* __restrict__ seed = ix.seed;
+  const int k = USE_SEED ? ix.seed_k : 1, W = (L + 31) / 32;
+  const uint32_t cA = (uint32_t)ix.prefix_sums[1], cC = (uint32_t)ix.prefix_sums[2], cG = (uint32_t)ix.prefix_sums[3],
+                 cN = (uint32_t)ix.prefix_sums[4], cT = (uint32_t)ix.prefix_sums[5], cEnd = (uint32_t)ix.prefix_sums[6];
+  bool have = q < n, fresh = true;
+  uint64_t w = 0;
+  uint32_t sp = 1, ep = 0;
+  int i = 0;
+  while (__any(have)) {
+    if (have) {
+      const uint64_t* qw = queries + q * W;
+      if (fresh) {
+        const int first = L - k;  // letters first .. L-1 form the seed window (leftmost letter least significant)
+        const int a = first >> 5, sh = 2 * (first & 31);
+        uint64_t win = qw[a] >> sh;
+        if (sh && a + 1 < W) win |= qw[a + 1] << (64 - sh);
+        if (USE_SEED) {
+          const SeedEntry e = seed[(uint32_t)(win & ((1ull << (2 * k)) - 1))];
+          sp = e.cnt ? e.sp : 1u;
+          ep = e.cnt ? e.sp + e.cnt - 1u : 0u;
+        } else {
+          const uint32_t c = (uint32_t)win & 3u;  // k == 1: the window is the last letter
+          sp = c == 0 ? cA : (c == 1 ? cC : (c == 2 ? cG : cT));
+          ep = (c == 0 ? cC : (c == 1 ? cG : (c == 2 ? cN : cEnd))) - 1;
+        }
+        i = first;
+        w = i > 0 ? qw[(i - 1) >> 5] : 0;
+        fresh = false;
+      } else {
+        i--;
+        const uint32_t c = (uint32_t)(w >> (2 * (i & 31))) & 3u;
+        const uint32_t cl = c == 0 ? cA : (c == 1 ? cC : (c == 2 ? cG : cT));
+        quad_step(blocks, cl, sp, ep, c, l);
+        if ((i & 31) == 0 && i > 0) w = qw[(i - 1) >> 5];
+      }
+      if (sp > ep || i == 0) {
+        if (l == 0) {
+          counts[q] = sp > ep ? 0ull : (uint64_t)(ep - sp) + 1ull;
+          if (range_start) range_start[q] = sp;
+        }
+        q += nquads;
+        have = q < n;
+        fresh = true;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// locate v2: tiles of hits, per-lane walk state machines, optional dense device SA
+// ------------------------------------------------------------------------------------------------
+constexpr int LOC_TILE = 1024;  // hits per tile (one 256-thread block at a time)
+constexpr int LOC_QCAP = 1024;  // query (offset, start) pairs cached in LDS per tile
+
+// value of the suffix array at a sampled row: the file's bit-packed samples (rows r % sa_ratio == 0) or the
+// dense device array (rows r % dense_ratio == 0, u32 entries) built by densify_sa_kernel
+__device__ __forceinline__ bool row_is_sampled(const DevIndex& ix, const uint32_t* dense, uint32_t dense_ratio, uint64_t row) {
+  return dense ? (row % dense_ratio == 0) : (row % ix.sa_ratio == 0);
+}
+__device__ __forceinline__ uint64_t row_sample(const DevIndex& ix, const uint32_t* dense, uint32_t dense_ratio, uint64_t row) {
+  return dense ? (uint64_t)dense[row / dense_ratio] : sa_sample(ix, row / ix.sa_ratio);
+}
+
+// dense[j] = SA[j * dense_ratio] for every j, recovered by LF walks to the file's samples (src/fm_index.rs:521-534)
+template <int A>
+__global__ __launch_bounds__(256) void densify_sa_kernel(DevIndex ix, uint32_t dense_ratio, uint64_t nentries, uint32_t* __restrict__ dense) {
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < nentries; j += stride) {
+    uint64_t row = j * dense_ratio, steps = 0;
+    while (row % ix.sa_ratio != 0) { row = backstep_scalar<A>(ix, row); steps++; }
+    dense[j] = (uint32_t)((sa_sample(ix, row / ix.sa_ratio) + steps) % ix.bwt_len);
+  }
+}
+
+// hits [tile * LOC_TILE, ...) handed out by an atomic tile head; inside a tile every lane is a small state
+// machine (take a hit -> walk one backstep per iteration -> emit), so lanes whose walk ends early take the next
+// hit instead of idling behind the longest walk of the wave.
+template <int A>
+__global__ __launch_bounds__(256) void locate_tile_kernel(DevIndex ix, const uint64_t* __restrict__ range_start, int rs_stride,
+                                                          const uint64_t* __restrict__ hit_off, uint64_t n, uint64_t total,
+                                                          const uint32_t* __restrict__ dense, uint32_t dense_ratio,
+                                                          uint64_t* __restrict__ gpos, uint64_t* __restrict__ pos,
+                                                          unsigned long long* __restrict__ tile_counter) {
+  __shared__ uint64_t s_off[LOC_QCAP + 1];
+  __shared__ uint64_t s_sp[LOC_QCAP];
+  __shared__ unsigned long long s_tile;
+  __shared__ uint64_t s_q[2];
+  __shared__ int s_cursor;
+  const uint64_t ntiles = (total + LOC_TILE - 1) / LOC_TILE;
+  for (;;) {
+    if (threadIdx.x == 0) { s_tile = atomicAdd(tile_counter, 1ull); s_cursor = 0; }
+    __syncthreads();
+    const uint64_t tile = s_tile;
+    if (tile >= ntiles) break;
+    const uint64_t h0 = tile * LOC_TILE;
+    const int tn = (int)(total - h0 < (uint64_t)LOC_TILE ? total - h0 : (uint64_t)LOC_TILE);
+    if (threadIdx.x < 2) {  // queries holding the first and the last hit of the tile
+      const uint64_t h = threadIdx.x == 0 ? h0 : h0 + tn - 1;
+      uint64_t lo = 0, hi = n;
+      while (hi - lo > 1) { uint64_t mid = (lo + hi) >> 1; if (hit_off[mid] <= h) lo = mid; else hi = mid; }
+      s_q[threadIdx.x] = lo;
+    }
+    __syncthreads();
+    const uint64_t q0 = s_q[0], nq = s_q[1] - s_q[0] + 1;
+    const bool cached = nq <= (uint64_t)LOC_QCAP;
+    if (cached) {
+      for (uint64_t t = threadIdx.x; t <= nq; t += blockDim.x) s_off[t] = hit_off[q0 + t];
+      for (uint64_t t = threadIdx.x; t < nq; t += blockDim.x) s_sp[t] = range_start[(q0 + t) * rs_stride];
+    }
+    __syncthreads();
+    bool need = true;
+    uint64_t h = 0, row = 0, steps = 0;
+    for (;;) {
+      if (need) {
+        const int t = atomicAdd(&s_cursor, 1);
+        if (t >= tn) break;
+        h = h0 + t;
+        uint64_t lo = 0, hi = cached ? nq : n;  // largest query with offset <= h (skips queries without hits)
+        if (cached) {
+          while (hi - lo > 1) { uint64_t mid = (lo + hi) >> 1; if (s_off[mid] <= h) lo = mid; else hi = mid; }
+          row = s_sp[lo] + (h - s_off[lo]);
+        } else {
+          while (hi - lo > 1) { uint64_t mid = (lo + hi) >> 1; if (hit_off[mid] <= h) lo = mid; else hi = mid; }
+          row = range_start[lo * rs_stride] + (h - hit_off[lo]);
+        }
+        steps = 0;
+        need = false;
+      }
+      if (row_is_sampled(ix, dense, dense_ratio, row)) {
+        const uint64_t g = (row_sample(ix, dense, dense_ratio, row) + steps) % ix.bwt_len;  // src/fm_index.rs:534
+        gpos[h] = g;
+        if (pos) {
+          uint64_t a = 0, z = ix.nseq;  // largest i with seq_starts[i] <= g
+          while (z - a > 1) { uint64_t mid = (a + z) >> 1; if (ix.seq_starts[mid] <= g) a = mid; else z = mid; }
+          pos[2 * h] = a;
+          pos[2 * h + 1] = g - (ix.nseq ? ix.seq_starts[a] : 0);
+        }
+        need = true;
+      } else {
+        row = backstep_scalar<A>(ix, row);
+        steps++;
+      }
+    }
+    __syncthreads();
   }
 }
 

@@ -338,8 +338,49 @@ class FmIndex:
     def dev_scan_scratch_bytes(self, n) -> int:
         return int(self._L.awry_dev_scan_scratch_bytes(n))
 
-    def dev_locate(self, d_ranges, d_hit_off, n, total, d_gpos, d_pos=None, stream=None, slot=0):
-        _check(self._L.awry_dev_locate(self._h, slot, d_ranges, d_hit_off, n, total, d_gpos, d_pos, stream))
+    def dev_locate(self, d_ranges, d_hit_off, n, total, d_gpos, d_pos=None, stream=None, slot=0, range_stride=2):
+        _check(self._L.awry_dev_locate(self._h, slot, d_ranges, range_stride, d_hit_off, n, total, d_gpos, d_pos, stream))
+
+    def dev_count_nt2_long(self, d_words, n, L, d_counts, d_range_start=None, use_seed=True, stream=None, slot=0):
+        _check(self._L.awry_dev_count_nt2_long(self._h, slot, d_words, n, L, d_counts, d_range_start, 1 if use_seed else 0, stream))
+
+    def set_locate_sa_ratio(self, ratio: int):
+        """device-side SA density for locate (0 = the file's samples); results do not depend on it"""
+        _check(self._L.awry_set_locate_sa_ratio(self._h, ratio))
+
+    def locate_sa_ratio(self) -> int:
+        return self._L.awry_locate_sa_ratio(self._h)
+
+    def locate_reads_nt2(self, q2d: np.ndarray, use_seed=True, slot=0):
+        """fixed-length ACGT reads uint8[n, L] of any L through the packed pipeline:
+        pack -> seeded quad count -> scan -> tile locate.  -> (hit_off, global_pos, pos[total, 2])"""
+        q2d = np.ascontiguousarray(q2d, dtype=np.uint8)
+        n, L = q2d.shape
+        W = (L + 31) // 32
+        d_ascii = self.dev_upload(q2d.reshape(-1), slot)
+        bufs = [d_ascii]
+        try:
+            d_words, d_counts, d_sp, d_bad = (self.dev_malloc(8 * n * W, slot), self.dev_malloc(8 * n, slot), self.dev_malloc(8 * n, slot),
+                                              self.dev_malloc(8, slot))
+            d_off, d_scr = self.dev_malloc(8 * (n + 1), slot), self.dev_malloc(self.dev_scan_scratch_bytes(n), slot)
+            bufs += [d_words, d_counts, d_sp, d_bad, d_off, d_scr]
+            self.dev_memset(d_bad, 0, 8, slot)
+            self.dev_pack_nt2(d_ascii, n, L, d_words, d_bad, None, slot)
+            self.dev_count_nt2_long(d_words, n, L, d_counts, d_sp, use_seed, None, slot)
+            self.dev_scan_counts(d_counts, n, d_off, d_scr, None, slot)
+            self.dev_synchronize(slot)
+            if int(self.dev_download(d_bad, (1,), np.uint64, slot)[0]):
+                raise AwryError(ERR_INVALID_QUERY, "reads contain bytes outside ACGT; use parallel_locate")
+            off = self.dev_download(d_off, (n + 1,), np.uint64, slot)
+            total = int(off[-1])
+            d_g, d_p = self.dev_malloc(8 * max(total, 1), slot), self.dev_malloc(16 * max(total, 1), slot)
+            bufs += [d_g, d_p]
+            self.dev_locate(d_sp, d_off, n, total, d_g, d_p, None, slot, range_stride=1)
+            self.dev_synchronize(slot)
+            return off, self.dev_download(d_g, (total,), np.uint64, slot), self.dev_download(d_p, (total, 2), np.uint64, slot)
+        finally:
+            for p in bufs:
+                self.dev_free(p, slot)
 
     def dev_timer_begin(self, stream=None, slot=0):
         _check(self._L.awry_dev_timer_begin(self._h, slot, stream))

@@ -79,6 +79,11 @@ int awry_set_devices(awry_index_t *idx, const int *device_ids, int n_devices);
  * -1 picks the default.  Takes effect immediately on all replicas. */
 int awry_set_seed_kmer_len(awry_index_t *idx, int k);
 int awry_seed_kmer_len(const awry_index_t *idx);
+/* device-side SA sampling used by locate (performance knob only; locations do not depend on it): 0 = walk to the
+ * file's row samples (suffix_array_compression_ratio, default), r >= 1 = additionally keep SA[j r] as u32 in HBM
+ * (r = 1: one read per hit, no LF walk; GRCh38: 12.4 GB).  Needs bwt_len < 2^32. */
+int awry_set_locate_sa_ratio(awry_index_t *idx, int ratio);
+int awry_locate_sa_ratio(const awry_index_t *idx);
 int awry_num_devices(const awry_index_t *idx);
 
 /* ---- batch queries --------------------------------------------------------------------------------- */
@@ -129,7 +134,7 @@ uint8_t awry_symbol_index(int alphabet, uint8_t ascii); /* Symbol::new_ascii(..)
 /* ---- device-resident API: pointers are device memory on replica `slot`'s GPU, work is queued on
  *      `stream` (a hipStream_t, NULL = default stream) and NOT synchronised --------------------------------- */
 int awry_replica_device(const awry_index_t *idx, int slot);
-/* fixed-length ACGT k-mers (L <= 32), ASCII n*L bytes -> n packed u64 words (letter j in bits 2j..2j+1);
+/* fixed-length ACGT reads, ASCII n*L bytes -> n * ceil(L/32) packed u64 words (letter j in word j/32, bits 2(j%32));
  * *d_bad (u64 on device, caller-zeroed) counts queries with other bytes */
 int awry_dev_pack_nt2(awry_index_t *idx, int slot, const void *d_ascii, uint64_t n, int L, void *d_words,
                       void *d_bad, void *stream);
@@ -147,9 +152,15 @@ int awry_dev_count_ascii(awry_index_t *idx, int slot, const void *d_qbytes, cons
 uint64_t awry_dev_scan_scratch_bytes(uint64_t n);
 int awry_dev_scan_counts(awry_index_t *idx, int slot, const void *d_counts, uint64_t n, void *d_hit_off,
                          void *d_scratch, void *stream);
-/* backtrace total hits: ranges[2n], hit_off[n+1] -> global_pos[total], pos[total] (nullable) */
-int awry_dev_locate(awry_index_t *idx, int slot, const void *d_ranges, const void *d_hit_off, uint64_t n,
+/* backtrace `total` hits: d_ranges[q * range_stride] = first row of query q's range (stride 2 = the (start,end)
+ * pairs of awry_dev_count_ascii, stride 1 = the starts of awry_dev_count_nt2_long), hit_off[n+1] ->
+ * global_pos[total], pos[total] (nullable) */
+int awry_dev_locate(awry_index_t *idx, int slot, const void *d_ranges, int range_stride, const void *d_hit_off, uint64_t n,
                     uint64_t total, void *d_global_pos, void *d_pos, void *stream);
+/* packed reads of any length: W = ceil(L/32) u64 words per query (letter j in word j/32, bits 2(j%32), as written by
+ * awry_dev_pack_nt2); counts[n] and, if non-null, range_start[n] (first BWT row of each range) for awry_dev_locate */
+int awry_dev_count_nt2_long(awry_index_t *idx, int slot, const void *d_words, uint64_t n, int L, void *d_counts,
+                            void *d_range_start, int use_seed, void *stream);
 /* plumbing for callers without a HIP binding of their own */
 int awry_dev_malloc(awry_index_t *idx, int slot, uint64_t bytes, void **d_out);
 int awry_dev_free(awry_index_t *idx, int slot, void *d);

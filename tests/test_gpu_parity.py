@@ -213,3 +213,41 @@ def test_gpu_construction_degenerate_texts():
         assert np.array_equal(gpu.device_block_words(), host.device_block_words()), t[:20]
         assert np.array_equal(gpu.sa_words(), host.sa_words()) and gpu.sentinel_row() == host.sentinel_row()
         assert np.array_equal(gpu.prefix_sums(), host.prefix_sums())
+
+
+@pytest.mark.parametrize("L", [33, 50, 64, 65, 101, 150])
+def test_long_packed_reads_count_and_locate(oracle, L):
+    """multi-word packed reads through the quad kernel + tile locate, against the oracle (same order)"""
+    text, st, hd = synth.make_text(300000, 0, 41, 4, 0.05)
+    ix = gpu_index(text, 0, 8, 0, st, hd)
+    oi = oracle.OracleIndex.from_text(text, 0, 8, 0, st, hd)
+    q2d = np.concatenate([synth.sampled_queries(text, 600, L, L), synth.random_queries(200, L, 0, L + 1)])
+    q2d[5] = q2d[4]  # duplicates are independent queries
+    qb, qo = synth.fixed_to_csr(q2d)
+    ooff, ogpos, opos, _ = oi.parallel_locate(qb, qo, 4)
+    for k in (-1, 0, 5):
+        ix.set_seed_kmer_len(k)
+        off, gpos, pos = ix.locate_reads_nt2(q2d, True)
+        assert np.array_equal(off, ooff) and np.array_equal(gpos, ogpos) and np.array_equal(pos, opos), (L, k)
+
+
+@pytest.mark.parametrize("alphabet", [0, 1])
+def test_dense_device_sa_does_not_change_locations(oracle, tmp_path, alphabet):
+    """awry_set_locate_sa_ratio is a performance knob: every density gives the oracle's locations, also on a
+    loaded index (whose dense SA is recovered by LF walks to the file's samples)"""
+    text, st, hd = synth.make_text(120000, alphabet, 19, 5, 0.05)
+    ix = gpu_index(text, alphabet, 8, 0, st, hd)
+    oi = oracle.OracleIndex.from_text(text, alphabet, 8, 0, st, hd)
+    qb, qo = synth.fixed_to_csr(synth.sampled_queries(text, 800, 7 if alphabet else 12, 3, False, alphabet))
+    qb2, qo2 = synth.fixed_to_csr(synth.random_queries(300, 4 if alphabet else 7, alphabet, 4))
+    want = [oi.parallel_locate(qb, qo, 4)[:3], oi.parallel_locate(qb2, qo2, 4)[:3]]
+    p = str(tmp_path / "d.awry")
+    ix.save(p)
+    loaded = FmIndex.load(p).set_devices([0])
+    for idx in (ix, loaded):
+        assert idx.locate_sa_ratio() == 8
+        for r in (1, 2, 3, 8, 16, 0):
+            idx.set_locate_sa_ratio(r)
+            for (b, o), w in zip(((qb, qo), (qb2, qo2)), want):
+                got = idx.parallel_locate_csr(b, o)
+                assert all(np.array_equal(x, y) for x, y in zip(got, w)), r

@@ -44,6 +44,81 @@ def unpack_nt2(words, L):
     return out
 
 
+def locate_benchmark(ix, text, torch, dev, stream, n_reads, read_len, oi=None, cores=1):
+    """SA-locate hits/s (BASELINE.json's second metric; configs[2] shape: reads sampled from the text, exact match).
+    Pipeline on the device: packed reads -> seeded quad count (+range starts) -> scan -> tile locate.  Timed per phase
+    with HIP events, for the file's row samples (ratio 8, mean ~7 LF steps per hit) and for the dense device SA."""
+    from tests import synth
+    reads = synth.sampled_queries(text, n_reads, read_len, 4242)
+    W = (read_len + 31) // 32
+    d_ascii = torch.from_numpy(reads.reshape(-1)).to(dev)
+    d_words = torch.zeros(n_reads * W, dtype=torch.int64, device=dev)
+    d_bad = torch.zeros(1, dtype=torch.int64, device=dev)
+    d_counts = torch.zeros(n_reads, dtype=torch.int64, device=dev)
+    d_sp = torch.zeros(n_reads, dtype=torch.int64, device=dev)
+    d_off = torch.zeros(n_reads + 1, dtype=torch.int64, device=dev)
+    d_scr = torch.zeros(ix.dev_scan_scratch_bytes(n_reads) // 8 + 1, dtype=torch.int64, device=dev)
+    ix.dev_pack_nt2(d_ascii.data_ptr(), n_reads, read_len, d_words.data_ptr(), d_bad.data_ptr(), stream, 0)
+    torch.cuda.synchronize()
+    assert int(d_bad.item()) == 0
+
+    def timed(fn, reps=3):
+        fn()
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(reps):
+            fn()
+        b.record()
+        torch.cuda.synchronize()
+        return a.elapsed_time(b) / reps
+
+    ms_count = timed(lambda: ix.dev_count_nt2_long(d_words.data_ptr(), n_reads, read_len, d_counts.data_ptr(), d_sp.data_ptr(), True, stream, 0))
+    ms_scan = timed(lambda: ix.dev_scan_counts(d_counts.data_ptr(), n_reads, d_off.data_ptr(), d_scr.data_ptr(), stream, 0))
+    total = int(d_off[-1].item())
+    assert bool((d_counts >= 1).all()), "a read sampled from the text was not found"
+    d_g = torch.zeros(max(total, 1), dtype=torch.int64, device=dev)
+    d_p = torch.zeros(2 * max(total, 1), dtype=torch.int64, device=dev)
+    out = {"reads": n_reads, "read_len": read_len, "hits": total, "count_phase_ms": ms_count, "scan_ms": ms_scan,
+           "count_phase_reads_per_s": n_reads / (ms_count * 1e-3), "seed_k": ix.seed_kmer_len()}
+    ref = None
+    for ratio in (0, 1):  # 0 = the file's samples (suffix_array_compression_ratio 8), 1 = dense device SA
+        ix.set_locate_sa_ratio(ratio)
+        ms = timed(lambda: ix.dev_locate(d_sp.data_ptr(), d_off.data_ptr(), n_reads, total, d_g.data_ptr(), d_p.data_ptr(), stream, 0, 1))
+        g = d_g[:total].cpu().numpy().view(np.uint64)
+        if ref is None:
+            ref = g.copy()
+            # size-independent property at full size: every located position holds its read
+            qi = np.repeat(np.arange(n_reads), d_counts.cpu().numpy())
+            chk = np.random.default_rng(1).integers(0, total, size=min(total, 200_000))
+            win = text[g[chk].astype(np.int64)[:, None] + np.arange(read_len)[None, :]]
+            assert np.array_equal(win, reads[qi[chk]]), "a located position does not hold its read"
+        else:
+            assert np.array_equal(ref, g), "dense-SA locate differs from the sampled-SA locate"
+        steps = 7.0 if ratio == 0 else 0.0  # mean LF steps per hit with row sampling at ratio 8 (SURVEY.md a-16)
+        alg = total * (104.0 * steps + 8.0 + 16.0)
+        out["sa_ratio_%d" % ix.locate_sa_ratio()] = {
+            "locate_kernel_ms": ms, "hits_per_s": total / (ms * 1e-3), "algorithmic_GBs": alg / (ms * 1e-3) / 1e9,
+            "frac_of_hbm_peak": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "end_to_end_reads_per_s_device_resident": n_reads / ((ms_count + ms_scan + ms) * 1e-3)}
+    ix.set_locate_sa_ratio(0)
+    if oi is not None:
+        ns = min(n_reads, 200_000)
+        qb, qo = synth.fixed_to_csr(reads[:ns])
+        tp = time.perf_counter()
+        ooff, ogpos, opos, otally = oi.parallel_locate(qb, qo, cores)
+        dt = time.perf_counter() - tp
+        nh = int(ooff[-1])
+        off_gpu = d_off[:ns + 1].cpu().numpy().view(np.uint64)
+        parity = bool(np.array_equal(off_gpu, ooff) and np.array_equal(ref[:nh], ogpos))
+        out["cpu_baseline"] = {"hits_per_s": nh / dt, "reads_per_s": ns / dt, "cores": cores, "kind": "port",
+                               "sample": "first %d reads, %d hits, %.1f s" % (ns, nh, dt),
+                               "backsteps_per_hit": otally["backsteps"] / max(nh, 1), "steps_per_read": otally["steps"] / ns,
+                               "gpu_matches_oracle_on_sample": parity}
+        assert parity, "GPU locate differs from the oracle on the sample"
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -56,6 +131,7 @@ def main():
     ap.add_argument("--seed-k", type=int, default=-1, help="device seed-table k (-1 = library default, 0 = off)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline duration (0 = skip)")
     ap.add_argument("--no-variants", action="store_true")
+    ap.add_argument("--locate-reads", type=int, default=5_000_000, help="101-bp reads in the locate measurement (N=1)")
     ap.add_argument("--sweep-seed-k", default="", help="comma list of seed k to time on rank 0 before the run (stderr)")
     args = ap.parse_args()
 
@@ -170,6 +246,21 @@ def main():
                      "census_per_launch": {"seed_probes": probes, "steps": steps_exec, "block_reads": blocks}},
     }
 
+    # HBM traffic per launch from the committed rocprofv3 PMC passes of this exact configuration (null otherwise)
+    try:
+        tkey = "%s|nq=%d|L=%d|seed_k=%d|kernel=count_nt2_quad_kernel" % (args.workload if not args.text_len else "custom", nq, L, ix.seed_kmer_len())
+        tentry = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get(tkey)
+        if tentry:
+            result["roofline"]["traffic"] = tentry["traffic_bytes_per_launch"]
+            result["roofline"]["traffic_source"] = tentry["source"]
+    except (OSError, ValueError):
+        pass
+    # the ceiling that actually binds this access pattern: random 128-B line requests (profiles/r01_gather_calibration.txt)
+    lines = probes + blocks + nq * (8.0 + 8.0) / 128.0
+    result["roofline"]["random_line_rate"] = {"achieved_Glines_s": lines / (kernel_ms * 1e-3) / 1e9, "measured_ceiling_Glines_s": 53.0,
+                                              "note": "seed probe + ranked blocks + coalesced share of query/result words; ceiling = "
+                                                      "tools/calib_gather.hip on a 2 GiB table (45 on 16 GiB)"}
+
     if rank == 0 and world == 1:
         extra = {}
         if not args.no_variants:
@@ -244,7 +335,8 @@ def main():
             sample = min(nq, 10_000_000)
             w0 = batches[W % n_batches][:sample].cpu().numpy().view(np.uint64)
             qb, qo = synth.fixed_to_csr(unpack_nt2(w0, L))
-            probe_n = min(sample, 500_000)
+            probe_n = min(sample, 2_000_000)
+            oi.parallel_count(qb[:probe_n * L], qo[:probe_n + 1], cores)  # warm the thread pool / page tables
             tp = time.perf_counter()
             oi.parallel_count(qb[:probe_n * L], qo[:probe_n + 1], cores)
             rate = probe_n / (time.perf_counter() - tp)
@@ -268,6 +360,12 @@ def main():
                 log("PARITY FAILURE: GPU counts differ from the oracle on the sample")
                 print(json.dumps(result))
                 sys.exit(3)
+        else:
+            oi, cores = None, 1
+        if not args.no_variants:
+            del batches
+            torch.cuda.empty_cache()
+            result["locate"] = locate_benchmark(ix, text, torch, dev, stream, args.locate_reads, 101, oi, cores)
 
     if rank == 0:
         print(json.dumps(result), flush=True)

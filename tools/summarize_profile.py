@@ -18,15 +18,18 @@ def find(sub, pat):
 # kernel stats
 for f in find("trace", "*kernel_stats.csv"):
     rows = list(csv.DictReader(open(f)))
-    out["kernel_stats"] = [{k: r[k] for k in r if k in ("Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs")} for r in rows[:12]]
+    keep = [r for i, r in enumerate(rows) if i < 8 or any(t in r["Name"] for t in ("count_nt2", "locate", "count_scalar"))]
+    out["kernel_stats"] = [{k: (r[k][:160] if k == "Name" else r[k]) for k in r if k in ("Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs")} for r in keep]
 
 # per-dispatch durations of the hot kernel from the kernel trace
 for f in find("trace", "*kernel_trace.csv"):
     d = defaultdict(list)
     for r in csv.DictReader(open(f)):
         d[r["Kernel_Name"]].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    ranked = sorted(d.items(), key=lambda kv: -sum(kv[1]))
+    keep = [kv for i, kv in enumerate(ranked) if i < 8 or any(t in kv[0] for t in ("count_nt2", "locate", "count_scalar"))]
     out["kernel_trace_avg_us"] = {k[:90]: {"calls": len(v), "avg_us": sum(v) / len(v) / 1e3, "min_us": min(v) / 1e3, "max_us": max(v) / 1e3}
-                                  for k, v in sorted(d.items(), key=lambda kv: -sum(kv[1]))[:10]}
+                                  for k, v in keep}
 
 # PMC passes: counter value per dispatch, averaged per kernel
 for sub in ("pmc_fetch", "pmc_write", "pmc_l2"):

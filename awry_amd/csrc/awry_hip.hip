@@ -130,6 +130,20 @@ int grid_for(const Replica& r, uint64_t work_items, int per_block, int blocks_pe
   return (int)std::max<uint64_t>(1, std::min(want, cap));
 }
 
+// which instantiation serves awry_dev_count_nt2: 0 strided quads, 1 LDS-staged chunks, 2 groups of four
+std::atomic<int> g_count_kernel{-1};
+int count_kernel_mode() {
+  int m = g_count_kernel.load();
+  if (m >= 0) return m;
+  const char* e = getenv("AWRY_COUNT_KERNEL");
+  if (e && !strcmp(e, "strided")) return 0;
+  if (e && !strcmp(e, "chunk")) return 1;
+  if (e && !strcmp(e, "quad4")) return 2;
+  // measured on MI355X, GRCh38-scale, 10 M random 31-mers per launch (tools/ab_count.py):
+  //   seed k=16: strided 17.9, quad4 19.4, chunk 13.8 G queries/s;  k=14: 10.1 / 10.1 / 9.9
+  return 2;
+}
+
 bool narrow(const HostIndex& h) { return h.bwt_len < (1ull << 32) - 512; }
 
 int default_seed_k(const HostIndex& h) {
@@ -317,7 +331,8 @@ void launch_count_nt2(Replica& r, const uint64_t* d_words, uint64_t n, int L, ui
   // AWRY_COUNT_KERNEL=chunk selects the LDS-staged variant (count_nt2_chunk_kernel).  Measured on MI355X it is
   // equal at seed k=14 and 23% slower at k=16 (GRCh38-scale): the strided kernel's query words already arrive
   // as L2 hits, so staging only removes the partial-line result writes and pays chunk drain + refill for it.
-  static const bool use_chunk = getenv("AWRY_COUNT_KERNEL") && !strcmp(getenv("AWRY_COUNT_KERNEL"), "chunk");
+  const int kmode = count_kernel_mode();
+  const bool use_chunk = kmode == 1;
   if (use_chunk) {
     unsigned long long* ctr = next_counter(r, s);
     if (d_tally) {
@@ -326,6 +341,18 @@ void launch_count_nt2(Replica& r, const uint64_t* d_words, uint64_t n, int L, ui
     } else {
       if (seeded) hipLaunchKernelGGL((count_nt2_chunk_kernel<true, false>), g, b, 0, s, r.dev, d_words, n, L, d_counts, ctr, d_tally);
       else hipLaunchKernelGGL((count_nt2_chunk_kernel<false, false>), g, b, 0, s, r.dev, d_words, n, L, d_counts, ctr, d_tally);
+    }
+    HIP_CHECK(hipGetLastError());
+    return;
+  }
+  if (kmode == 2) {  // groups of 4 consecutive queries per quad: whole-sector result writes
+    const dim3 g4(grid_for(r, n, 256));
+    if (d_tally) {
+      if (seeded) hipLaunchKernelGGL((count_nt2_quad4_kernel<true, true>), g4, b, 0, s, r.dev, d_words, n, L, d_counts, d_tally);
+      else hipLaunchKernelGGL((count_nt2_quad4_kernel<false, true>), g4, b, 0, s, r.dev, d_words, n, L, d_counts, d_tally);
+    } else {
+      if (seeded) hipLaunchKernelGGL((count_nt2_quad4_kernel<true, false>), g4, b, 0, s, r.dev, d_words, n, L, d_counts, d_tally);
+      else hipLaunchKernelGGL((count_nt2_quad4_kernel<false, false>), g4, b, 0, s, r.dev, d_words, n, L, d_counts, d_tally);
     }
     HIP_CHECK(hipGetLastError());
     return;
@@ -617,6 +644,8 @@ int awry_set_seed_kmer_len(awry_index_t* idx, int k) {
     }
   });
 }
+
+int awry_debug_set_count_kernel(int mode) { g_count_kernel.store(mode); return AWRY_OK; }
 
 int awry_seed_kmer_len(const awry_index_t* idx) { return idx && !idx->reps.empty() ? idx->reps[0]->seed_k : 0; }
 int awry_num_devices(const awry_index_t* idx) { return idx ? (int)idx->reps.size() : 0; }

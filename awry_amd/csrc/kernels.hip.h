@@ -430,6 +430,78 @@ __global__ __launch_bounds__(256) void count_nt2_quad_kernel(DevIndex ix, const 
   }
 }
 
+// "quad4" variant of the hot kernel: a quad owns GROUPS of 4 consecutive queries (32 contiguous bytes in and out).
+// Lane t of the quad loads query 4m+t and keeps result 4m+t, so the group is read with one 32-B request and
+// written back as one whole 32-B sector; the strided kernel above writes every 8-B count on its own, which
+// rocprofv3 shows as 5x write amplification (WRITE_SIZE 40 B per query) and ~0.65 extra L2 misses per query.
+template <bool USE_SEED, bool TALLY>
+__global__ __launch_bounds__(256) void count_nt2_quad4_kernel(DevIndex ix, const uint64_t* __restrict__ queries, uint64_t n, int L,
+                                                              uint64_t* __restrict__ counts, unsigned long long* __restrict__ tally) {
+  const int lane = threadIdx.x & 63, l = lane & 3;
+  const uint64_t nquads = ((uint64_t)gridDim.x * blockDim.x) >> 2;
+  const uint64_t ngroups = (n + 3) >> 2;
+  uint64_t m = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 2;  // group index
+  const uint64_t* __restrict__ blocks = ix.blocks;
+  const SeedEntry* __restrict__ seed = ix.seed;
+  const int k = USE_SEED ? ix.seed_k : 1;
+  const uint32_t cA = (uint32_t)ix.prefix_sums[1], cC = (uint32_t)ix.prefix_sums[2], cG = (uint32_t)ix.prefix_sums[3],
+                 cN = (uint32_t)ix.prefix_sums[4], cT = (uint32_t)ix.prefix_sums[5], cEnd = (uint32_t)ix.prefix_sums[6];
+  bool have = m < ngroups;
+  uint64_t wq = (have && 4 * m + l < n) ? queries[4 * m + l] : 0;  // this lane's query of the group
+  int nvalid = have ? (int)(n - 4 * m < 4 ? n - 4 * m : 4) : 0;
+  int t = 0;              // query of the group being searched
+  bool fresh = true;
+  uint64_t w = 0, res = 0;
+  uint32_t sp = 1, ep = 0;
+  int i = 0;
+  uint32_t t_probe = 0, t_step = 0, t_blk = 0;
+
+  while (__any(have)) {
+    if (have) {
+      if (fresh) {
+        w = __shfl(wq, (lane & ~3) | t, 64);
+        if (USE_SEED) {
+          const uint32_t sidx = (uint32_t)((w >> (2 * (L - k))) & ((1ull << (2 * k)) - 1));
+          const SeedEntry e = seed[sidx];
+          sp = e.cnt ? e.sp : 1u;
+          ep = e.cnt ? e.sp + e.cnt - 1u : 0u;
+          if (TALLY) t_probe++;
+        } else {
+          const uint32_t c = (uint32_t)(w >> (2 * (L - 1))) & 3u;
+          sp = c == 0 ? cA : (c == 1 ? cC : (c == 2 ? cG : cT));
+          ep = (c == 0 ? cC : (c == 1 ? cG : (c == 2 ? cN : cEnd))) - 1;
+        }
+        i = L - k;
+        fresh = false;
+      } else {
+        i--;
+        const uint32_t c = (uint32_t)(w >> (2 * i)) & 3u;
+        const uint32_t cl = c == 0 ? cA : (c == 1 ? cC : (c == 2 ? cG : cT));
+        if (TALLY) { t_step++; t_blk += ((sp - 1) >> 8) == (ep >> 8) ? 1u : 2u; }
+        quad_step(blocks, cl, sp, ep, c, l);
+      }
+      if (sp > ep || i == 0) {
+        if (l == t) res = sp > ep ? 0ull : (uint64_t)(ep - sp) + 1ull;
+        t++;
+        fresh = true;
+        if (t == nvalid) {  // group finished: one 32-B store, then the next group
+          if (l < nvalid) counts[4 * m + l] = res;
+          m += nquads;
+          have = m < ngroups;
+          t = 0;
+          nvalid = have ? (int)(n - 4 * m < 4 ? n - 4 * m : 4) : 0;
+          wq = (have && 4 * m + l < n) ? queries[4 * m + l] : 0;
+        }
+      }
+    }
+  }
+  if (TALLY && l == 0) {
+    atomicAdd(&tally[0], (unsigned long long)t_probe);
+    atomicAdd(&tally[1], (unsigned long long)t_step);
+    atomicAdd(&tally[2], (unsigned long long)t_blk);
+  }
+}
+
 // v2 of the hot kernel: the query and result streams are staged through LDS in wave-private chunks so that
 // both move as whole 128-B lines (v1 fetched one line per 8-B query word and wrote one partial line per
 // 8-B result: 2 of its ~4 line requests per query).  A wave grabs a chunk of CHUNK consecutive queries with

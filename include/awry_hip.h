@@ -79,6 +79,9 @@ int awry_set_devices(awry_index_t *idx, const int *device_ids, int n_devices);
  * -1 picks the default.  Takes effect immediately on all replicas. */
 int awry_set_seed_kmer_len(awry_index_t *idx, int k);
 int awry_seed_kmer_len(const awry_index_t *idx);
+/* A/B switch for the packed-k-mer count kernel (process-wide; -1 default, 0 strided quads, 1 LDS-staged chunks,
+ * 2 groups of four queries per quad).  All variants return identical counts. */
+int awry_debug_set_count_kernel(int mode);
 /* device-side SA sampling used by locate (performance knob only; locations do not depend on it): 0 = walk to the
  * file's row samples (suffix_array_compression_ratio, default), r >= 1 = additionally keep SA[j r] as u32 in HBM
  * (r = 1: one read per hit, no LF walk; GRCh38: 12.4 GB).  Needs bwt_len < 2^32. */

@@ -427,7 +427,104 @@ void check_status(const ChunkBuffers& cb, uint64_t first_query) {
     }
 }
 
+// pins a caller-owned host range for the duration of a batch so that H2D/D2H run as real async DMA
+struct HostPin {
+  void* p = nullptr;
+  HostPin(const void* ptr, size_t bytes) {
+    if (ptr && bytes >= (8u << 20) && hipHostRegister(const_cast<void*>(ptr), bytes, hipHostRegisterDefault) == hipSuccess) p = const_cast<void*>(ptr);
+    else (void)hipGetLastError();
+  }
+  ~HostPin() { if (p) (void)hipHostUnregister(p); }
+};
+
+// Fast path of parallel_count for the common k-mer batch: nucleotide index, every query the same length L,
+// letters in ACGT.  Chunks flow through two stream lanes (H2D ASCII -> pack on device -> packed quad kernel ->
+// D2H counts) so transfers overlap kernels; no per-query offsets cross PCIe.  A chunk that turns out to hold
+// other bytes (N, IUPAC codes, '$' ...) is re-run through the generic kernel, so results never depend on the path.
+struct PackedLane {
+  hipStream_t s = nullptr;
+  hipEvent_t done = nullptr;
+  DevBuf<uint8_t> ascii;
+  DevBuf<uint64_t> words, counts;
+  DevBuf<unsigned long long> bad;
+  unsigned long long* h_bad = nullptr;  // pinned
+  Shard chunk{0, 0};
+  bool busy = false;
+  ~PackedLane() {
+    if (s) (void)hipStreamDestroy(s);
+    if (done) (void)hipEventDestroy(done);
+    if (h_bad) (void)hipHostFree(h_bad);
+  }
+};
+
+bool shard_fixed_length(const uint64_t* qoff, Shard sh, uint64_t& L) {
+  if (sh.hi <= sh.lo) return false;
+  L = qoff[sh.lo + 1] - qoff[sh.lo];
+  if (L == 0 || L > 4096) return false;
+  for (uint64_t i = sh.lo; i < sh.hi; i++)
+    if (qoff[i + 1] - qoff[i] != L) return false;
+  return true;
+}
+
+void launch_count_nt2(Replica& r, const uint64_t* d_words, uint64_t n, int L, uint64_t* d_counts, bool use_seed, hipStream_t s,
+                      unsigned long long* d_tally);
+void count_shard_generic(Replica& r, const uint8_t* qbytes, const uint64_t* qoff, Shard sh, uint64_t* counts_out);
+
+void count_shard_packed(Replica& r, const uint8_t* qbytes, const uint64_t* qoff, Shard sh, uint64_t L, uint64_t* counts_out) {
+  const uint64_t CH = 4u << 20;  // queries per chunk
+  const int W = (int)((L + 31) / 32);
+  HostPin pin_in(qbytes + qoff[sh.lo], (sh.hi - sh.lo) * L), pin_out(counts_out + sh.lo, (sh.hi - sh.lo) * 8);
+  PackedLane lanes[2];
+  std::vector<Shard> redo;
+  auto retire = [&](PackedLane& ln) {
+    if (!ln.busy) return;
+    HIP_CHECK(hipEventSynchronize(ln.done));
+    if (*ln.h_bad) redo.push_back(ln.chunk);
+    ln.busy = false;
+  };
+  for (auto& ln : lanes) {
+    HIP_CHECK(hipStreamCreateWithFlags(&ln.s, hipStreamNonBlocking));
+    HIP_CHECK(hipEventCreateWithFlags(&ln.done, hipEventDisableTiming));
+    HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&ln.h_bad), 8, hipHostMallocDefault));
+    const uint64_t cap = std::min<uint64_t>(CH, sh.hi - sh.lo);
+    ln.ascii.alloc(cap * L + 16);
+    ln.words.alloc(cap * W);
+    ln.counts.alloc(cap);
+    ln.bad.alloc(1);
+  }
+  int which = 0;
+  for (uint64_t lo = sh.lo; lo < sh.hi; lo += CH, which ^= 1) {
+    PackedLane& ln = lanes[which];
+    retire(ln);
+    const uint64_t hi = std::min(sh.hi, lo + CH), n = hi - lo;
+    ln.chunk = Shard{lo, hi};
+    HIP_CHECK(hipMemcpyAsync(ln.ascii.p, qbytes + qoff[lo], n * L, hipMemcpyHostToDevice, ln.s));
+    HIP_CHECK(hipMemsetAsync(ln.bad.p, 0, 8, ln.s));
+    hipLaunchKernelGGL(pack_nt2_kernel, dim3(grid_for(r, n, 256)), dim3(256), 0, ln.s, ln.ascii.p, n, (int)L, ln.words.p, ln.bad.p);
+    HIP_CHECK(hipGetLastError());
+    if (L <= 32) launch_count_nt2(r, ln.words.p, n, (int)L, ln.counts.p, true, ln.s, nullptr);
+    else launch_count_nt2_long(r, ln.words.p, n, (int)L, ln.counts.p, nullptr, true, ln.s);
+    HIP_CHECK(hipMemcpyAsync(counts_out + lo, ln.counts.p, n * 8, hipMemcpyDeviceToHost, ln.s));
+    HIP_CHECK(hipMemcpyAsync(ln.h_bad, ln.bad.p, 8, hipMemcpyDeviceToHost, ln.s));
+    HIP_CHECK(hipEventRecord(ln.done, ln.s));
+    ln.busy = true;
+  }
+  for (auto& ln : lanes) retire(ln);
+  for (Shard c : redo) count_shard_generic(r, qbytes, qoff, c, counts_out);  // also raises INVALID_QUERY where due
+}
+
 void count_shard(Replica& r, const uint8_t* qbytes, const uint64_t* qoff, Shard sh, uint64_t* counts_out) {
+  HIP_CHECK(hipSetDevice(r.device));
+  uint64_t L = 0;
+  static const bool no_fast = getenv("AWRY_HOST_PATH") && !strcmp(getenv("AWRY_HOST_PATH"), "generic");
+  if (!no_fast && r.dev.alphabet == NUCLEOTIDE && r.dev.bwt_len < (1ull << 32) - 512 && shard_fixed_length(qoff, sh, L)) {
+    count_shard_packed(r, qbytes, qoff, sh, L, counts_out);
+    return;
+  }
+  count_shard_generic(r, qbytes, qoff, sh, counts_out);
+}
+
+void count_shard_generic(Replica& r, const uint8_t* qbytes, const uint64_t* qoff, Shard sh, uint64_t* counts_out) {
   HIP_CHECK(hipSetDevice(r.device));
   ChunkBuffers cb;
   for (Shard c : chunk_queries(qoff, sh.lo, sh.hi)) {

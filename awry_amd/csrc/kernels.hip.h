@@ -135,9 +135,29 @@ __global__ __launch_bounds__(256) void count_scalar_kernel(DevIndex ix, const ui
     uint64_t sp = 1, ep = 0;
     if (st == Q_OK) {
       uint64_t i = e - 1;
-      int idx = lut[ascii[i]];
-      sp = ix.prefix_sums[idx];          // SearchRange::new, src/search.rs:43-48
-      ep = ix.prefix_sums[idx + 1] - 1;
+      bool seeded = false;
+      if (A == NUCLEOTIDE && ix.seed && e - b >= (uint64_t)ix.seed_k) {  // last k symbols all in ACGT -> one table probe
+        const int k = ix.seed_k;
+        uint32_t sidx = 0;
+        bool acgt = true;
+        for (int j = 0; j < k; j++) {
+          const int letter = nt_letter_of_index(lut[ascii[e - k + j]]);
+          acgt = acgt && letter >= 0;
+          sidx |= (uint32_t)(letter & 3) << (2 * j);  // leftmost letter of the window least significant
+        }
+        if (acgt) {
+          const SeedEntry se = ix.seed[sidx];
+          sp = se.cnt ? se.sp : 1;
+          ep = se.cnt ? (uint64_t)se.sp + se.cnt - 1 : 0;
+          i = e - k;
+          seeded = true;
+        }
+      }
+      if (!seeded) {
+        int idx = lut[ascii[i]];
+        sp = ix.prefix_sums[idx];          // SearchRange::new, src/search.rs:43-48
+        ep = ix.prefix_sums[idx + 1] - 1;
+      }
       while (i > b && sp <= ep) {        // emptiness is sticky, so stopping early never changes the count
         i--;
         step_scalar<A>(ix, sp, ep, lut[ascii[i]]);

@@ -251,3 +251,24 @@ def test_dense_device_sa_does_not_change_locations(oracle, tmp_path, alphabet):
             for (b, o), w in zip(((qb, qo), (qb2, qo2)), want):
                 got = idx.parallel_locate_csr(b, o)
                 assert all(np.array_equal(x, y) for x, y in zip(got, w)), r
+
+
+@pytest.mark.parametrize("L", [12, 31, 32, 40, 101])
+def test_host_batch_fast_path_equals_generic(oracle, L, monkeypatch):
+    """parallel_count on fixed-length batches takes the pipelined packed path; chunks with N / IUPAC / lower-case / U
+    fall back per chunk to the generic kernel.  Both must give the oracle's counts."""
+    text, st, hd = synth.make_text(400000, 0, 61, 3, 0.05)
+    ix = gpu_index(text, 0, 8, 0, st, hd)
+    oi = oracle.OracleIndex.from_text(text, 0, 8, 0, st, hd)
+    clean = np.concatenate([synth.sampled_queries(text, 3000, L, L), synth.random_queries(3000, L, 0, L + 1)])
+    dirty = clean.copy()
+    dirty[7, 3] = ord("N"); dirty[100, 0] = ord("u"); dirty[2999, L - 1] = ord("R"); dirty[11] = np.frombuffer(bytes(dirty[11]).lower(), np.uint8)
+    for q2d in (clean, dirty):
+        qb, qo = synth.fixed_to_csr(q2d)
+        want, _ = oi.parallel_count(qb, qo, 4)
+        assert np.array_equal(ix.parallel_count_csr(qb, qo), want)
+    bad = clean.copy()
+    bad[5, 2] = ord("$")
+    with pytest.raises(AwryError) as e:
+        ix.parallel_count_csr(*synth.fixed_to_csr(bad))
+    assert e.value.code == ERR_INVALID_QUERY

@@ -1,0 +1,25 @@
+"""end-to-end throughput of the host boundary (ASCII queries in host memory -> counts in host memory).
+usage: time_host_api.py [text_len] [n_queries]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import awry_amd
+from tests import synth
+n = int(float(sys.argv[1])) if len(sys.argv) > 1 else 248_956_422
+nq = int(float(sys.argv[2])) if len(sys.argv) > 2 else 20_000_000
+text, st, hd = synth.make_text(n, 0, 0xA5A50002, 1, 0.05)
+ix = awry_amd.FmIndex.from_text(text, 0, 8, 0, st, hd).set_devices([0])
+for L in (31, 101):
+    q2d = synth.random_queries(nq if L == 31 else nq // 4, L, 0, 5)
+    qb, qo = synth.fixed_to_csr(q2d)
+    for rep in range(3):
+        t = time.perf_counter(); c = ix.parallel_count_csr(qb, qo); dt = time.perf_counter() - t
+    print("fixed L=%d: %d queries in %.1f ms -> %.1f M queries/s end-to-end (PCIe-inclusive, %.2f GB/s in)" % (L, len(q2d), dt * 1e3, len(q2d) / dt / 1e6, qb.nbytes / dt / 1e9), flush=True)
+    os.environ["X"] = "1"
+# generic path: ragged lengths
+lens = np.random.default_rng(1).integers(20, 40, size=nq // 4)
+qo = np.zeros(len(lens) + 1, dtype=np.uint64); qo[1:] = np.cumsum(lens)
+qb = synth.NT[np.random.default_rng(2).integers(0, 4, size=int(qo[-1]), dtype=np.uint8)]
+for rep in range(2):
+    t = time.perf_counter(); c = ix.parallel_count_csr(qb, qo); dt = time.perf_counter() - t
+print("ragged 20..39: %d queries in %.1f ms -> %.1f M queries/s (generic kernel)" % (len(lens), dt * 1e3, len(lens) / dt / 1e6))

@@ -272,3 +272,48 @@ def test_host_batch_fast_path_equals_generic(oracle, L, monkeypatch):
     with pytest.raises(AwryError) as e:
         ix.parallel_count_csr(*synth.fixed_to_csr(bad))
     assert e.value.code == ERR_INVALID_QUERY
+
+
+@pytest.mark.parametrize("n,recs", [(248_956_422, 1), (3_100_000_000, 25)], ids=["chr1_scale", "grch38_scale"])
+def test_full_scale_properties(n, recs):
+    """BASELINE.json's full sizes (index built on the GPU in seconds): size-independent properties.
+    * every k-mer sampled from the text is found, at its own position, and every located window equals the query;
+    * count == number of locations; the seeded, unseeded and generic kernels agree;
+    * letter totals in the prefix sums equal the text's histogram (checksum of the BWT)."""
+    text, st, hd = synth.make_text(n, 0, 0xA5A50000 + 2, recs, 0.05)
+    ix = gpu_index(text, 0, 8, 0, st, hd)
+    hist = np.bincount(text, minlength=256)
+    ps = ix.prefix_sums()
+    assert ps[-1] == n + 1
+    assert [int(ps[i + 1] - ps[i]) for i in range(6)] == [1, hist[65], hist[67], hist[71], hist[78], hist[84]]
+    L, m = 31, 20000
+    rng = np.random.default_rng(3)
+    p = rng.integers(0, n - L, size=4 * m)
+    win = text[p[:, None] + np.arange(L)[None, :]]
+    ok = ~(win == ord("N")).any(axis=1)
+    p, present = p[ok][:m], win[ok][:m]
+    q2d = np.concatenate([present, synth.random_queries(m, L, 0, 6)])
+    qb, qo = synth.fixed_to_csr(q2d)
+    seeded = ix.count_kmers_nt2(q2d, True)
+    assert (seeded[:len(present)] >= 1).all()
+    assert np.array_equal(seeded, ix.count_kmers_nt2(q2d, False))
+    d_q, d_o = ix.dev_upload(qb), ix.dev_upload(qo)
+    d_c = ix.dev_malloc(8 * len(q2d))
+    ix.dev_count_ascii(d_q, d_o, len(q2d), d_c)
+    ix.dev_synchronize()
+    assert np.array_equal(seeded, ix.dev_download(d_c, (len(q2d),), np.uint64))
+    for ptr in (d_q, d_o, d_c):
+        ix.dev_free(ptr)
+    assert np.array_equal(seeded, ix.parallel_count_csr(qb, qo))  # host boundary (packed fast path)
+    for ratio in (0, 4):
+        ix.set_locate_sa_ratio(ratio)
+        off, gpos, pos = ix.locate_reads_nt2(q2d)
+        assert np.array_equal(np.diff(off), seeded)
+        qi = np.repeat(np.arange(len(q2d)), seeded.astype(np.int64))
+        assert np.array_equal(text[gpos.astype(np.int64)[:, None] + np.arange(L)[None, :]], q2d[qi])
+        first = off[:len(present)].astype(np.int64)
+        own = np.array([p[i] in gpos[off[i]:off[i + 1]] for i in range(0, len(present), 97)])
+        assert own.all()
+        starts = np.array(st, dtype=np.uint64)
+        si = np.searchsorted(starts, gpos, side="right") - 1
+        assert np.array_equal(pos[:, 0], si.astype(np.uint64)) and np.array_equal(pos[:, 1], gpos - starts[si])

@@ -143,11 +143,15 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         log("warning: WORLD_SIZE %d != --gpus %d; using WORLD_SIZE" % (world, args.gpus))
+    # AWRY_BENCH_BACKEND=gloo + fewer GPUs than ranks is a rehearsal mode for the N > 1 code path on a 1-GPU box
+    backend = os.environ.get("AWRY_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group(backend, rank=rank, world_size=world)
 
     def barrier():
         if world > 1:
@@ -223,7 +227,7 @@ def main():
     probes, steps_exec, blocks = [int(x) / K for x in tally.cpu().tolist()]
     alg_bytes = 16.0 * probes + 104.0 * blocks + nq * (8.0 + 8.0)  # probe 16 B, block 104 B, query 8 B, result 8 B
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed_max = float(t.item())

@@ -85,6 +85,7 @@ struct Replica {
   DevBuf<uint64_t> blocks, sa_words, seq_starts;
   DevBuf<SeedEntry> seed;
   DevBuf<unsigned long long> chunk_counters;  // ring of work-queue heads, one per in-flight count / locate launch
+  DevBuf<uint32_t> text4;                     // 4-bit text for seed-and-verify (device-only accelerator)
   DevBuf<uint32_t> dense_sa;                  // SA[j * dense_ratio] as u32 (device-only accelerator for locate)
   uint32_t dense_ratio = 0;                   // 0 = use the file's bit-packed samples
   std::atomic<unsigned> launch_seq{0};
@@ -97,7 +98,7 @@ struct Replica {
       if (stream) (void)hipStreamDestroy(stream);
       if (ev0) (void)hipEventDestroy(ev0);
       if (ev1) (void)hipEventDestroy(ev1);
-      blocks.reset(); sa_words.reset(); seq_starts.reset(); seed.reset(); chunk_counters.reset(); dense_sa.reset();
+      blocks.reset(); sa_words.reset(); seq_starts.reset(); seed.reset(); chunk_counters.reset(); dense_sa.reset(); text4.reset();
     }
   }
 };
@@ -109,6 +110,7 @@ struct awry_index {
   std::vector<std::unique_ptr<Replica>> reps;
   int seed_k_request = -1;      // -1 = default policy
   int dense_ratio_request = 0;  // 0 = locate walks to the file's SA samples
+  int verify_request = -1;      // < 0: seed-and-verify off; >= 0: LF steps before switching to text comparison
 };
 
 namespace {
@@ -188,6 +190,7 @@ void build_seed(awry_index* ix, Replica& r, int k) {
 }
 
 void build_dense_sa(awry_index* ix, Replica& r, int ratio);
+void build_verify(awry_index* ix, Replica& r, int after_steps);
 
 std::unique_ptr<Replica> make_replica(awry_index* ix, int device) {
   int ndev = 0;
@@ -227,8 +230,13 @@ std::unique_ptr<Replica> make_replica(awry_index* ix, int device) {
   d.sa_ratio = (uint32_t)h.sa_ratio;
   d.alphabet = h.alphabet;
   d.seed_k = 0;
+  d.dense_sa = nullptr;
+  d.text4 = nullptr;
+  d.dense_ratio = 0;
+  d.verify_after = 0;
   build_seed(ix, *r, ix->seed_k_request < 0 ? default_seed_k(h) : ix->seed_k_request);
   build_dense_sa(ix, *r, ix->dense_ratio_request);
+  if (ix->verify_request >= 0) build_verify(ix, *r, ix->verify_request);
   return r;
 }
 
@@ -291,8 +299,12 @@ void launch_locate(Replica& r, const uint64_t* d_range_start, int rs_stride, con
 
 // dense device SA for locate: ratio 0 = off (walk to the file's samples), r >= 1 = keep SA[j r] for every j as u32
 void build_dense_sa(awry_index* ix, Replica& r, int ratio) {
+  r.text4.reset();  // the verify shortcut rides on the ratio-1 dense SA; it is re-enabled by build_verify()
+  r.dev.text4 = nullptr;
   r.dense_sa.reset();
   r.dense_ratio = 0;
+  r.dev.dense_sa = nullptr;
+  r.dev.dense_ratio = 0;
   if (ratio <= 0) return;
   require(ix->host.bwt_len < (1ull << 32), "a dense device SA needs bwt_len < 2^32");
   if ((uint64_t)ratio >= ix->host.sa_ratio && ix->host.sa_ratio % (uint64_t)ratio == 0 && (uint64_t)ratio == ix->host.sa_ratio) return;
@@ -305,6 +317,28 @@ void build_dense_sa(awry_index* ix, Replica& r, int ratio) {
   HIP_CHECK(hipStreamSynchronize(r.stream));
   r.dense_sa = std::move(d);
   r.dense_ratio = (uint32_t)ratio;
+  r.dev.dense_sa = r.dense_sa.p;
+  r.dev.dense_ratio = r.dense_ratio;
+}
+
+// seed-and-verify for packed nucleotide reads: needs the ratio-1 dense SA and the 4-bit text, both recovered from the
+// index on the device.  after_steps < 0 switches it off.
+void build_verify(awry_index* ix, Replica& r, int after_steps) {
+  r.text4.reset();
+  r.dev.text4 = nullptr;
+  r.dev.verify_after = 0;
+  if (after_steps < 0) return;
+  require(ix->host.alphabet == NUCLEOTIDE && narrow(ix->host), "seed-and-verify needs a nucleotide index with bwt_len < 2^32");
+  if (r.dense_ratio != 1) build_dense_sa(ix, r, 1);
+  const uint64_t nwords = (ix->host.bwt_len + 7) / 8 + 8;  // + slack: a 32-symbol window read touches 5 words
+  DevBuf<uint32_t> t(nwords);
+  HIP_CHECK(hipMemsetAsync(t.p, 0, nwords * 4, r.stream));
+  hipLaunchKernelGGL(text4_scatter_kernel<NUCLEOTIDE>, dim3(grid_for(r, ix->host.bwt_len, 256)), dim3(256), 0, r.stream, r.dev, t.p);
+  HIP_CHECK(hipGetLastError());
+  HIP_CHECK(hipStreamSynchronize(r.stream));
+  r.text4 = std::move(t);
+  r.dev.text4 = r.text4.p;
+  r.dev.verify_after = (uint32_t)after_steps;
 }
 
 void launch_count_nt2_long(Replica& r, const uint64_t* d_words, uint64_t n, int L, uint64_t* d_counts, uint64_t* d_range_start,
@@ -313,10 +347,18 @@ void launch_count_nt2_long(Replica& r, const uint64_t* d_words, uint64_t n, int 
   require(r.dev.bwt_len < (1ull << 32) - 512, "the quad kernel needs bwt_len < 2^32");
   require(L >= 1 && L <= 1 << 20, "packed read length out of range");
   if (n == 0) return;
+  if (r.dev.text4 && r.dev.dense_ratio == 1) {
+    const bool sd = use_seed && r.seed_k > 0 && r.seed_k <= L;
+    const dim3 g(grid_for(r, n * 4, 256)), b(256);
+    if (sd) hipLaunchKernelGGL((count_nt2_reads_kernel<true, true>), g, b, 0, s, r.dev, d_words, n, L, d_counts, d_range_start);
+    else hipLaunchKernelGGL((count_nt2_reads_kernel<false, true>), g, b, 0, s, r.dev, d_words, n, L, d_counts, d_range_start);
+    HIP_CHECK(hipGetLastError());
+    return;
+  }
   const bool seeded = use_seed && r.seed_k > 0 && r.seed_k <= L;
   const dim3 g(grid_for(r, n * 4, 256)), b(256);
-  if (seeded) hipLaunchKernelGGL(count_nt2_long_quad_kernel<true>, g, b, 0, s, r.dev, d_words, n, L, d_counts, d_range_start);
-  else hipLaunchKernelGGL(count_nt2_long_quad_kernel<false>, g, b, 0, s, r.dev, d_words, n, L, d_counts, d_range_start);
+  if (seeded) hipLaunchKernelGGL((count_nt2_reads_kernel<true, false>), g, b, 0, s, r.dev, d_words, n, L, d_counts, d_range_start);
+  else hipLaunchKernelGGL((count_nt2_reads_kernel<false, false>), g, b, 0, s, r.dev, d_words, n, L, d_counts, d_range_start);
   HIP_CHECK(hipGetLastError());
 }
 
@@ -954,6 +996,17 @@ int awry_set_locate_sa_ratio(awry_index_t* idx, int ratio) {
     for (size_t s = 0; s < idx->reps.size(); s++) build_dense_sa(idx, replica(idx, (int)s), ratio);
   });
 }
+int awry_set_verify(awry_index_t* idx, int after_steps) {
+  return guarded([&] {
+    require(idx != nullptr, "null index");
+    require(after_steps >= -1 && after_steps <= 1000, "verify threshold out of range");
+    idx->verify_request = after_steps;
+    if (after_steps >= 0) idx->dense_ratio_request = 1;
+    for (size_t s = 0; s < idx->reps.size(); s++) build_verify(idx, replica(idx, (int)s), after_steps);
+  });
+}
+int awry_verify_enabled(const awry_index_t* idx) { return idx && !idx->reps.empty() && idx->reps[0]->dev.text4 != nullptr; }
+
 int awry_locate_sa_ratio(const awry_index_t* idx) {
   if (!idx || idx->reps.empty()) return 0;
   return idx->reps[0]->dense_ratio ? (int)idx->reps[0]->dense_ratio : (int)idx->host.sa_ratio;

@@ -664,58 +664,133 @@ __global__ __launch_bounds__(256) void pack_nt2_kernel(const uint8_t* __restrict
   }
 }
 
-// Packed reads of any length (W = ceil(L/32) words per query, same letter order as above) with the final range
-// written out for locate: the quad design of count_nt2_quad_kernel, the current word re-read every 32 letters.
-template <bool USE_SEED>
-__global__ __launch_bounds__(256) void count_nt2_long_quad_kernel(DevIndex ix, const uint64_t* __restrict__ queries, uint64_t n, int L,
-                                                                  uint64_t* __restrict__ counts, uint64_t* __restrict__ range_start) {
+// 16 packed 2-bit letters (low 32 bits of x) -> 16 nibbles holding the same letters
+__device__ __forceinline__ uint64_t spread_letters16(uint64_t x) {
+  x &= 0xFFFFFFFFull;
+  x = (x | (x << 16)) & 0x0000FFFF0000FFFFull;
+  x = (x | (x << 8)) & 0x00FF00FF00FF00FFull;
+  x = (x | (x << 4)) & 0x0F0F0F0F0F0F0F0Full;
+  x = (x | (x << 2)) & 0x3333333333333333ull;
+  return x;
+}
+
+struct Text20 { uint32_t w[5]; };  // 5 consecutive u32 of the 4-bit text: any 32 symbols at any nibble offset
+
+// Does text[g + 32 j0' .. ) equal this lane's 32-letter query word?  Lane l of the quad compares window symbols
+// [128 c + 32 l, +32) of a window of `len` symbols starting at text position g; returns 1 on a mismatch.
+__device__ __forceinline__ uint32_t verify_part(const uint32_t* __restrict__ text4, uint64_t g, int len, int c, int l, uint64_t qword) {
+  const int j0 = 128 * c + 32 * l;
+  const int m = len - j0 < 0 ? 0 : (len - j0 > 32 ? 32 : len - j0);  // symbols this lane checks
+  if (m == 0) return 0u;
+  const uint64_t t0 = g + (uint64_t)j0;
+  const Text20 t = *reinterpret_cast<const Text20*>(text4 + (t0 >> 3));
+  const int sh = 4 * (int)(t0 & 7);
+  const uint64_t a0 = (uint64_t)t.w[0] | ((uint64_t)t.w[1] << 32), a1 = (uint64_t)t.w[2] | ((uint64_t)t.w[3] << 32), a2 = t.w[4];
+  const uint64_t lo = sh ? (a0 >> sh) | (a1 << (64 - sh)) : a0;
+  const uint64_t hi = sh ? (a1 >> sh) | (a2 << (64 - sh)) : a1;
+  const uint64_t qlo = spread_letters16(qword), qhi = spread_letters16(qword >> 32);
+  const uint64_t mlo = m >= 16 ? ~0ull : ((1ull << (4 * m)) - 1);
+  const uint64_t mhi = m <= 16 ? 0ull : (m >= 32 ? ~0ull : ((1ull << (4 * (m - 16))) - 1));
+  return (((lo ^ qlo) & mlo) | ((hi ^ qhi) & mhi)) ? 1u : 0u;
+}
+
+// Packed reads of any length (W = ceil(L/32) words per query, letter j in word j/32, bits 2(j%32)): the quad design
+// of the k-mer kernels, the current word re-read every 32 letters, the final range handed on for locate.
+//
+// VERIFY adds seed-and-verify, an MI355X-first shortcut the 288 GB of HBM pay for (dense SA + 4-bit text resident):
+// once the range has shrunk to <= 8 rows, the remaining i symbols are not matched by i dependent LF steps (i random
+// lines) but by comparing them with the text in front of each candidate suffix: 1 SA read + the i/2 contiguous bytes
+// of text per candidate.  The rows that survive are exactly the rows whose suffixes extend to the whole query, in
+// the same relative order as the final range (the suffixes share everything after the seed part), so counts and
+// locations are unchanged; the locate pass receives the verified candidates instead of a row range (RS_* words).
+template <bool USE_SEED, bool VERIFY>
+__global__ __launch_bounds__(256) void count_nt2_reads_kernel(DevIndex ix, const uint64_t* __restrict__ queries, uint64_t n, int L,
+                                                              uint64_t* __restrict__ counts, uint64_t* __restrict__ range_start) {
   const int l = threadIdx.x & 3;
   const uint64_t nquads = ((uint64_t)gridDim.x * blockDim.x) >> 2;
   uint64_t q = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 2;
   const uint64_t* __restrict__ blocks = ix.blocks;
   const SeedEntry* __restrict__ seed = ix.seed;
+  const uint32_t* __restrict__ dense = ix.dense_sa;
+  const uint32_t* __restrict__ text4 = ix.text4;
   const int k = USE_SEED ? ix.seed_k : 1, W = (L + 31) / 32;
+  const int verify_after = (int)ix.verify_after;
   const uint32_t cA = (uint32_t)ix.prefix_sums[1], cC = (uint32_t)ix.prefix_sums[2], cG = (uint32_t)ix.prefix_sums[3],
                  cN = (uint32_t)ix.prefix_sums[4], cT = (uint32_t)ix.prefix_sums[5], cEnd = (uint32_t)ix.prefix_sums[6];
   bool have = q < n, fresh = true;
   uint64_t w = 0;
   uint32_t sp = 1, ep = 0;
-  int i = 0;
+  int i = 0, steps_done = 0;
+  // verify state (quad-uniform): mode 0 = LF steps, 1 = read SA of candidate vj, 2 = compare text chunk vc
+  int mode = 0, vj = 0, vc = 0;
+  uint32_t vmask = 0, vp = 0;
   while (__any(have)) {
     if (have) {
       const uint64_t* qw = queries + q * W;
-      if (fresh) {
-        const int first = L - k;  // letters first .. L-1 form the seed window (leftmost letter least significant)
-        const int a = first >> 5, sh = 2 * (first & 31);
-        uint64_t win = qw[a] >> sh;
-        if (sh && a + 1 < W) win |= qw[a + 1] << (64 - sh);
-        if (USE_SEED) {
-          const SeedEntry e = seed[(uint32_t)(win & ((1ull << (2 * k)) - 1))];
-          sp = e.cnt ? e.sp : 1u;
-          ep = e.cnt ? e.sp + e.cnt - 1u : 0u;
+      bool finished = false;
+      uint64_t out_count = 0, out_rs = 0;
+      if (mode == 0) {
+        if (fresh) {
+          const int first = L - k;  // letters first .. L-1 form the seed window (leftmost letter least significant)
+          const int a = first >> 5, sh = 2 * (first & 31);
+          uint64_t win = qw[a] >> sh;
+          if (sh && a + 1 < W) win |= qw[a + 1] << (64 - sh);
+          if (USE_SEED) {
+            const SeedEntry e = seed[(uint32_t)(win & ((1ull << (2 * k)) - 1))];
+            sp = e.cnt ? e.sp : 1u;
+            ep = e.cnt ? e.sp + e.cnt - 1u : 0u;
+          } else {
+            const uint32_t c = (uint32_t)win & 3u;  // k == 1: the window is the last letter
+            sp = c == 0 ? cA : (c == 1 ? cC : (c == 2 ? cG : cT));
+            ep = (c == 0 ? cC : (c == 1 ? cG : (c == 2 ? cN : cEnd))) - 1;
+          }
+          i = first;
+          steps_done = 0;
+          w = i > 0 ? qw[(i - 1) >> 5] : 0;
+          fresh = false;
         } else {
-          const uint32_t c = (uint32_t)win & 3u;  // k == 1: the window is the last letter
-          sp = c == 0 ? cA : (c == 1 ? cC : (c == 2 ? cG : cT));
-          ep = (c == 0 ? cC : (c == 1 ? cG : (c == 2 ? cN : cEnd))) - 1;
+          i--;
+          const uint32_t c = (uint32_t)(w >> (2 * (i & 31))) & 3u;
+          const uint32_t cl = c == 0 ? cA : (c == 1 ? cC : (c == 2 ? cG : cT));
+          quad_step(blocks, cl, sp, ep, c, l);
+          steps_done++;
+          if ((i & 31) == 0 && i > 0) w = qw[(i - 1) >> 5];
         }
-        i = first;
-        w = i > 0 ? qw[(i - 1) >> 5] : 0;
-        fresh = false;
-      } else {
-        i--;
-        const uint32_t c = (uint32_t)(w >> (2 * (i & 31))) & 3u;
-        const uint32_t cl = c == 0 ? cA : (c == 1 ? cC : (c == 2 ? cG : cT));
-        quad_step(blocks, cl, sp, ep, c, l);
-        if ((i & 31) == 0 && i > 0) w = qw[(i - 1) >> 5];
+        if (sp > ep || i == 0) {
+          finished = true;
+          out_count = sp > ep ? 0ull : (uint64_t)(ep - sp) + 1ull;
+          out_rs = (RS_PLAIN << RS_MODE_SHIFT) | sp;
+        } else if (VERIFY) {
+          const uint32_t cnt = ep - sp + 1u;
+          if (cnt <= 8u && (int)(3u * cnt) <= i && steps_done >= verify_after && i < 65536) { mode = 1; vj = 0; vmask = 0; }
+        }
+      } else if (mode == 1) {  // text position of candidate row sp + vj
+        vp = dense[sp + (uint32_t)vj];
+        if (vp >= (uint32_t)i) { mode = 2; vc = 0; }
+        else vj++;  // the suffix starts too close to the text's beginning to have i symbols in front
+      } else {      // compare window chunk vc of candidate vj
+        const uint64_t g = (uint64_t)vp - (uint64_t)i;
+        const int wi = 4 * vc + l;
+        const uint32_t bad = quad_sum(verify_part(text4, g, i, vc, l, wi < W ? qw[wi] : 0ull));
+        if (bad) { vj++; mode = 1; }
+        else if (128 * (vc + 1) < i) vc++;
+        else { vmask |= 1u << vj; vj++; mode = 1; }
       }
-      if (sp > ep || i == 0) {
+      if (VERIFY && mode == 1 && vj > (int)(ep - sp)) {  // all candidates checked
+        finished = true;
+        out_count = (uint64_t)__popc(vmask);
+        if (ep == sp && vmask) out_rs = (RS_SINGLE << RS_MODE_SHIFT) | ((uint64_t)vp - (uint64_t)i);
+        else out_rs = (RS_MULTI << RS_MODE_SHIFT) | (uint64_t)sp | ((uint64_t)i << 32) | ((uint64_t)vmask << 48);
+      }
+      if (finished) {
         if (l == 0) {
-          counts[q] = sp > ep ? 0ull : (uint64_t)(ep - sp) + 1ull;
-          if (range_start) range_start[q] = sp;
+          counts[q] = out_count;
+          if (range_start) range_start[q] = out_rs;
         }
         q += nquads;
         have = q < n;
         fresh = true;
+        mode = 0;
       }
     }
   }
@@ -744,6 +819,20 @@ __global__ __launch_bounds__(256) void densify_sa_kernel(DevIndex ix, uint32_t d
     uint64_t row = j * dense_ratio, steps = 0;
     while (row % ix.sa_ratio != 0) { row = backstep_scalar<A>(ix, row); steps++; }
     dense[j] = (uint32_t)((sa_sample(ix, row / ix.sa_ratio) + steps) % ix.bwt_len);
+  }
+}
+
+// the text as 4-bit codes, recovered from the index itself: T[SA[r] - 1] = BWT[r] (T[n-1] = '$' for the row with SA = 0).
+// Needs the dense SA at ratio 1.  Codes: A0 C1 G2 T3, everything else has bit 3 set and never equals a query letter.
+template <int A>
+__global__ __launch_bounds__(256) void text4_scatter_kernel(DevIndex ix, uint32_t* __restrict__ text4) {
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < ix.bwt_len; r += stride) {
+    const uint64_t v = ix.dense_sa[r];
+    const uint64_t p = v ? v - 1 : ix.bwt_len - 1;
+    const int letter = nt_letter_of_index(symbol_at<A>(ix, r));
+    const uint32_t code = letter >= 0 ? (uint32_t)letter : 8u;
+    if (code) atomicOr(&text4[p >> 3], code << (4 * (p & 7)));
   }
 }
 
@@ -783,26 +872,41 @@ __global__ __launch_bounds__(256) void locate_tile_kernel(DevIndex ix, const uin
       for (uint64_t t = threadIdx.x; t < nq; t += blockDim.x) s_sp[t] = range_start[(q0 + t) * rs_stride];
     }
     __syncthreads();
-    bool need = true;
-    uint64_t h = 0, row = 0, steps = 0;
+    bool need = true, direct = false;
+    uint64_t h = 0, row = 0, steps = 0, gd = 0;
     for (;;) {
       if (need) {
         const int t = atomicAdd(&s_cursor, 1);
         if (t >= tn) break;
         h = h0 + t;
         uint64_t lo = 0, hi = cached ? nq : n;  // largest query with offset <= h (skips queries without hits)
+        uint64_t rs, j;  // the query's range-start word and the index of this hit inside the query
         if (cached) {
           while (hi - lo > 1) { uint64_t mid = (lo + hi) >> 1; if (s_off[mid] <= h) lo = mid; else hi = mid; }
-          row = s_sp[lo] + (h - s_off[lo]);
+          rs = s_sp[lo];
+          j = h - s_off[lo];
         } else {
           while (hi - lo > 1) { uint64_t mid = (lo + hi) >> 1; if (hit_off[mid] <= h) lo = mid; else hi = mid; }
-          row = range_start[lo * rs_stride] + (h - hit_off[lo]);
+          rs = range_start[lo * rs_stride];
+          j = h - hit_off[lo];
+        }
+        const uint64_t rmode = rs >> RS_MODE_SHIFT;
+        direct = rmode != RS_PLAIN;
+        if (rmode == RS_SINGLE) {
+          gd = rs & ((1ull << 40) - 1);  // the count pass already verified this match against the text
+        } else if (rmode == RS_MULTI) {
+          uint32_t mask = (uint32_t)(rs >> 48) & 0xffu;
+          for (uint64_t t2 = 0; t2 < j; t2++) mask &= mask - 1;  // drop the j lowest set bits
+          const uint32_t cand = (uint32_t)__ffs((int)mask) - 1u;
+          gd = (uint64_t)ix.dense_sa[(uint32_t)rs + cand] - ((rs >> 32) & 0xffffull);
+        } else {
+          row = rs + j;
         }
         steps = 0;
         need = false;
       }
-      if (row_is_sampled(ix, dense, dense_ratio, row)) {
-        const uint64_t g = (row_sample(ix, dense, dense_ratio, row) + steps) % ix.bwt_len;  // src/fm_index.rs:534
+      if (direct || row_is_sampled(ix, dense, dense_ratio, row)) {
+        const uint64_t g = direct ? gd : (row_sample(ix, dense, dense_ratio, row) + steps) % ix.bwt_len;  // src/fm_index.rs:534
         gpos[h] = g;
         if (pos) {
           uint64_t a = 0, z = ix.nseq;  // largest i with seq_starts[i] <= g

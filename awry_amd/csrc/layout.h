@@ -75,6 +75,18 @@ struct DevIndex {
   uint64_t prefix_sums[24];   // C[i], src/fm_index.rs:233-240
   uint32_t sa_bits, sa_ratio;
   int32_t alphabet, seed_k;
+  // optional device-only accelerators (nullptr / 0 when absent); results never depend on them
+  const uint32_t* dense_sa;   // SA[j * dense_ratio] as u32
+  const uint32_t* text4;      // the text as 4-bit codes (A0 C1 G2 T3, 8 = anything else), 8 symbols per u32, LSB first
+  uint32_t dense_ratio;
+  uint32_t verify_after;      // seed-and-verify: switch from LF steps to text comparison after this many steps
 };
+
+// encoding of a query's "range start" word handed from the count pass to the locate pass
+constexpr uint64_t RS_MODE_SHIFT = 62;
+constexpr uint64_t RS_PLAIN = 0;   // low bits = first BWT row of the final range
+constexpr uint64_t RS_MULTI = 1;   // verified candidates: rows sp..sp+7, bit j of mask = candidate j matched;
+                                   //   bits 0..31 sp, 32..47 symbols left of the seed part (i), 48..55 mask
+constexpr uint64_t RS_SINGLE = 2;  // one verified match: low 40 bits = text position of the match
 
 }  // namespace awry

@@ -351,6 +351,13 @@ class FmIndex:
     def locate_sa_ratio(self) -> int:
         return self._L.awry_locate_sa_ratio(self._h)
 
+    def set_verify(self, after_steps: int):
+        """seed-and-verify for packed nucleotide reads (-1 = off); results do not depend on it"""
+        _check(self._L.awry_set_verify(self._h, after_steps))
+
+    def verify_enabled(self) -> bool:
+        return bool(self._L.awry_verify_enabled(self._h))
+
     def locate_reads_nt2(self, q2d: np.ndarray, use_seed=True, slot=0):
         """fixed-length ACGT reads uint8[n, L] of any L through the packed pipeline:
         pack -> seeded quad count -> scan -> tile locate.  -> (hit_off, global_pos, pos[total, 2])"""

@@ -101,6 +101,20 @@ def locate_benchmark(ix, text, torch, dev, stream, n_reads, read_len, oi=None, c
             "locate_kernel_ms": ms, "hits_per_s": total / (ms * 1e-3), "algorithmic_GBs": alg / (ms * 1e-3) / 1e9,
             "frac_of_hbm_peak": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
             "end_to_end_reads_per_s_device_resident": n_reads / ((ms_count + ms_scan + ms) * 1e-3)}
+    # seed-and-verify: dense SA + 4-bit text resident; the rest of a read is compared with the text, not LF-stepped
+    tv = time.time()
+    ix.set_verify(2)
+    build_s = time.time() - tv
+    ms_count_v = timed(lambda: ix.dev_count_nt2_long(d_words.data_ptr(), n_reads, read_len, d_counts.data_ptr(), d_sp.data_ptr(), True, stream, 0))
+    ms_scan_v = timed(lambda: ix.dev_scan_counts(d_counts.data_ptr(), n_reads, d_off.data_ptr(), d_scr.data_ptr(), stream, 0))
+    assert int(d_off[-1].item()) == total
+    ms_loc_v = timed(lambda: ix.dev_locate(d_sp.data_ptr(), d_off.data_ptr(), n_reads, total, d_g.data_ptr(), d_p.data_ptr(), stream, 0, 1))
+    assert np.array_equal(ref, d_g[:total].cpu().numpy().view(np.uint64)), "seed-and-verify locate differs"
+    out["seed_and_verify"] = {"count_phase_ms": ms_count_v, "count_phase_reads_per_s": n_reads / (ms_count_v * 1e-3),
+                              "locate_kernel_ms": ms_loc_v, "hits_per_s": total / (ms_loc_v * 1e-3),
+                              "end_to_end_reads_per_s_device_resident": n_reads / ((ms_count_v + ms_scan_v + ms_loc_v) * 1e-3),
+                              "accelerator_build_s": build_s, "identical_locations": True}
+    ix.set_verify(-1)
     ix.set_locate_sa_ratio(0)
     if oi is not None:
         ns = min(n_reads, 200_000)

@@ -87,6 +87,13 @@ int awry_debug_set_count_kernel(int mode);
  * (r = 1: one read per hit, no LF walk; GRCh38: 12.4 GB).  Needs bwt_len < 2^32. */
 int awry_set_locate_sa_ratio(awry_index_t *idx, int ratio);
 int awry_locate_sa_ratio(const awry_index_t *idx);
+/* seed-and-verify for packed nucleotide reads (performance knob only; counts and locations do not depend on it):
+ * keeps the ratio-1 dense SA and the text as 4-bit codes in HBM (GRCh38: 12.4 + 1.55 GB), both recovered from the
+ * index on the device.  Once a range holds <= 8 rows and `after_steps` LF steps have run, the rest of the read is
+ * compared with the text in front of each candidate instead of being matched by one dependent LF step per symbol.
+ * after_steps = -1 switches it off (default). */
+int awry_set_verify(awry_index_t *idx, int after_steps);
+int awry_verify_enabled(const awry_index_t *idx);
 int awry_num_devices(const awry_index_t *idx);
 
 /* ---- batch queries --------------------------------------------------------------------------------- */

@@ -317,3 +317,48 @@ def test_full_scale_properties(n, recs):
         starts = np.array(st, dtype=np.uint64)
         si = np.searchsorted(starts, gpos, side="right") - 1
         assert np.array_equal(pos[:, 0], si.astype(np.uint64)) and np.array_equal(pos[:, 1], gpos - starts[si])
+
+
+def repeat_text(seed):
+    """nucleotide text with repeated segments (so that several suffixes share long prefixes), N runs and 3 records"""
+    rng = np.random.default_rng(seed)
+    base = synth.NT[rng.integers(0, 4, size=60000, dtype=np.uint8)]
+    parts = [base, base[1000:21000], synth.NT[rng.integers(0, 4, size=5000, dtype=np.uint8)], base[500:30500], base[1000:9000],
+             np.full(300, ord("N"), np.uint8), base[40000:52000], base[1000:21000], base[40000:52000]]
+    body = np.concatenate(parts)
+    body[77777] = ord("N"); body[123456] = ord("N")
+    text = np.concatenate([body, np.frombuffer(b"$", np.uint8)])
+    return text, [0, 77778, 123457], ["r0", "r1", "r2"]
+
+
+@pytest.mark.parametrize("L", [20, 40, 101, 150, 300])
+@pytest.mark.parametrize("after", [0, 2])
+def test_seed_and_verify_does_not_change_results(oracle, L, after):
+    """awry_set_verify: text comparison instead of LF steps once a range is small -- same counts, same locations, same
+    order as the oracle, on a text with repeats (1..8 candidates per read), N runs and reads that start at text position 0"""
+    text, st, hd = repeat_text(5)
+    ix = gpu_index(text, 0, 8, 0, st, hd)
+    oi = oracle.OracleIndex.from_text(text, 0, 8, 0, st, hd)
+    rng = np.random.default_rng(L)
+    starts = np.concatenate([rng.integers(0, len(text) - L - 1, size=1500), [0, 1, 2, 1000, 40000, 77778, 123457], np.arange(60000 - L, 60010)])
+    reads = text[starts[:, None] + np.arange(L)[None, :]]
+    reads = reads[~((reads == ord("N")) | (reads == ord("$"))).any(axis=1)]
+    mut = reads[:300].copy()  # single mismatches at random places: mostly absent, sometimes another repeat copy
+    mut[np.arange(len(mut)), rng.integers(0, L, size=len(mut))] = synth.NT[rng.integers(0, 4, size=len(mut))]
+    q2d = np.concatenate([reads, mut, synth.random_queries(200, L, 0, 3)])
+    qb, qo = synth.fixed_to_csr(q2d)
+    ooff, ogpos, opos, _ = oi.parallel_locate(qb, qo, 4)
+    assert int(np.diff(ooff).max()) >= 4  # the text really has multi-candidate reads
+    for k in (-1, 6):
+        ix.set_seed_kmer_len(k)
+        ix.set_verify(-1)
+        base = ix.locate_reads_nt2(q2d)
+        ix.set_verify(after)
+        assert ix.verify_enabled() and ix.locate_sa_ratio() == 1
+        got = ix.locate_reads_nt2(q2d)
+        for x, y, z in zip(got, base, (ooff, ogpos, opos)):
+            assert np.array_equal(x, y) and np.array_equal(x, z), (L, after, k)
+        assert np.array_equal(ix.parallel_count_csr(qb, qo), np.diff(ooff))  # host fast path (long kernel, verify on)
+    ix.set_locate_sa_ratio(4)  # leaving ratio 1 switches verify off again
+    assert not ix.verify_enabled()
+    assert all(np.array_equal(x, y) for x, y in zip(ix.locate_reads_nt2(q2d), (ooff, ogpos, opos)))

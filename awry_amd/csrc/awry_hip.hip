@@ -389,13 +389,16 @@ void launch_count_nt2(Replica& r, const uint64_t* d_words, uint64_t n, int L, ui
   }
   if (kmode == 2) {  // groups of 4 consecutive queries per quad: whole-sector result writes
     const dim3 g4(grid_for(r, n, 256));
-    if (d_tally) {
-      if (seeded) hipLaunchKernelGGL((count_nt2_quad4_kernel<true, true>), g4, b, 0, s, r.dev, d_words, n, L, d_counts, d_tally);
-      else hipLaunchKernelGGL((count_nt2_quad4_kernel<false, true>), g4, b, 0, s, r.dev, d_words, n, L, d_counts, d_tally);
+    const bool verify = r.dev.text4 != nullptr && r.dev.dense_ratio == 1;
+#define AWRY_LAUNCH_QUAD4(S, T, V) hipLaunchKernelGGL((count_nt2_quad4_kernel<S, T, V>), g4, b, 0, s, r.dev, d_words, n, L, d_counts, d_tally)
+    if (verify) {
+      if (d_tally) { if (seeded) AWRY_LAUNCH_QUAD4(true, true, true); else AWRY_LAUNCH_QUAD4(false, true, true); }
+      else { if (seeded) AWRY_LAUNCH_QUAD4(true, false, true); else AWRY_LAUNCH_QUAD4(false, false, true); }
     } else {
-      if (seeded) hipLaunchKernelGGL((count_nt2_quad4_kernel<true, false>), g4, b, 0, s, r.dev, d_words, n, L, d_counts, d_tally);
-      else hipLaunchKernelGGL((count_nt2_quad4_kernel<false, false>), g4, b, 0, s, r.dev, d_words, n, L, d_counts, d_tally);
+      if (d_tally) { if (seeded) AWRY_LAUNCH_QUAD4(true, true, false); else AWRY_LAUNCH_QUAD4(false, true, false); }
+      else { if (seeded) AWRY_LAUNCH_QUAD4(true, false, false); else AWRY_LAUNCH_QUAD4(false, false, false); }
     }
+#undef AWRY_LAUNCH_QUAD4
     HIP_CHECK(hipGetLastError());
     return;
   }

@@ -450,11 +450,43 @@ __global__ __launch_bounds__(256) void count_nt2_quad_kernel(DevIndex ix, const 
   }
 }
 
+// 16 packed 2-bit letters (low 32 bits of x) -> 16 nibbles holding the same letters
+__device__ __forceinline__ uint64_t spread_letters16(uint64_t x) {
+  x &= 0xFFFFFFFFull;
+  x = (x | (x << 16)) & 0x0000FFFF0000FFFFull;
+  x = (x | (x << 8)) & 0x00FF00FF00FF00FFull;
+  x = (x | (x << 4)) & 0x0F0F0F0F0F0F0F0Full;
+  x = (x | (x << 2)) & 0x3333333333333333ull;
+  return x;
+}
+
+struct Text20 { uint32_t w[5]; };  // 5 consecutive u32 of the 4-bit text: any 32 symbols at any nibble offset
+
+// Does text[g + 32 j0' .. ) equal this lane's 32-letter query word?  Lane l of the quad compares window symbols
+// [128 c + 32 l, +32) of a window of `len` symbols starting at text position g; returns 1 on a mismatch.
+__device__ __forceinline__ uint32_t verify_part(const uint32_t* __restrict__ text4, uint64_t g, int len, int c, int l, uint64_t qword) {
+  const int j0 = 128 * c + 32 * l;
+  const int m = len - j0 < 0 ? 0 : (len - j0 > 32 ? 32 : len - j0);  // symbols this lane checks
+  if (m == 0) return 0u;
+  const uint64_t t0 = g + (uint64_t)j0;
+  const Text20 t = *reinterpret_cast<const Text20*>(text4 + (t0 >> 3));
+  const int sh = 4 * (int)(t0 & 7);
+  const uint64_t a0 = (uint64_t)t.w[0] | ((uint64_t)t.w[1] << 32), a1 = (uint64_t)t.w[2] | ((uint64_t)t.w[3] << 32), a2 = t.w[4];
+  const uint64_t lo = sh ? (a0 >> sh) | (a1 << (64 - sh)) : a0;
+  const uint64_t hi = sh ? (a1 >> sh) | (a2 << (64 - sh)) : a1;
+  const uint64_t qlo = spread_letters16(qword), qhi = spread_letters16(qword >> 32);
+  const uint64_t mlo = m >= 16 ? ~0ull : ((1ull << (4 * m)) - 1);
+  const uint64_t mhi = m <= 16 ? 0ull : (m >= 32 ? ~0ull : ((1ull << (4 * (m - 16))) - 1));
+  return (((lo ^ qlo) & mlo) | ((hi ^ qhi) & mhi)) ? 1u : 0u;
+}
+
 // "quad4" variant of the hot kernel: a quad owns GROUPS of 4 consecutive queries (32 contiguous bytes in and out).
 // Lane t of the quad loads query 4m+t and keeps result 4m+t, so the group is read with one 32-B request and
 // written back as one whole 32-B sector; the strided kernel above writes every 8-B count on its own, which
 // rocprofv3 shows as 5x write amplification (WRITE_SIZE 40 B per query) and ~0.65 extra L2 misses per query.
-template <bool USE_SEED, bool TALLY>
+// VERIFY: seed-and-verify as in count_nt2_reads_kernel (one candidate at a time, the <= 31 remaining letters are
+// one 16-B text window checked by lane 0); tally[3] += SA reads, tally[4] += text windows compared.
+template <bool USE_SEED, bool TALLY, bool VERIFY>
 __global__ __launch_bounds__(256) void count_nt2_quad4_kernel(DevIndex ix, const uint64_t* __restrict__ queries, uint64_t n, int L,
                                                               uint64_t* __restrict__ counts, unsigned long long* __restrict__ tally) {
   const int lane = threadIdx.x & 63, l = lane & 3;
@@ -464,6 +496,7 @@ __global__ __launch_bounds__(256) void count_nt2_quad4_kernel(DevIndex ix, const
   const uint64_t* __restrict__ blocks = ix.blocks;
   const SeedEntry* __restrict__ seed = ix.seed;
   const int k = USE_SEED ? ix.seed_k : 1;
+  const int verify_after = (int)ix.verify_after;
   const uint32_t cA = (uint32_t)ix.prefix_sums[1], cC = (uint32_t)ix.prefix_sums[2], cG = (uint32_t)ix.prefix_sums[3],
                  cN = (uint32_t)ix.prefix_sums[4], cT = (uint32_t)ix.prefix_sums[5], cEnd = (uint32_t)ix.prefix_sums[6];
   bool have = m < ngroups;
@@ -473,37 +506,65 @@ __global__ __launch_bounds__(256) void count_nt2_quad4_kernel(DevIndex ix, const
   bool fresh = true;
   uint64_t w = 0, res = 0;
   uint32_t sp = 1, ep = 0;
-  int i = 0;
-  uint32_t t_probe = 0, t_step = 0, t_blk = 0;
+  int i = 0, steps_done = 0;
+  int mode = 0, vj = 0;   // verify: 0 = LF steps, 1 = read SA of candidate vj, 2 = compare its text window
+  uint32_t vhits = 0, vp = 0;
+  uint32_t t_probe = 0, t_step = 0, t_blk = 0, t_vsa = 0, t_vtxt = 0;
 
   while (__any(have)) {
     if (have) {
-      if (fresh) {
-        w = __shfl(wq, (lane & ~3) | t, 64);
-        if (USE_SEED) {
-          const uint32_t sidx = (uint32_t)((w >> (2 * (L - k))) & ((1ull << (2 * k)) - 1));
-          const SeedEntry e = seed[sidx];
-          sp = e.cnt ? e.sp : 1u;
-          ep = e.cnt ? e.sp + e.cnt - 1u : 0u;
-          if (TALLY) t_probe++;
+      bool finished = false;
+      uint64_t out_count = 0;
+      if (!VERIFY || mode == 0) {
+        if (fresh) {
+          w = __shfl(wq, (lane & ~3) | t, 64);
+          if (USE_SEED) {
+            const uint32_t sidx = (uint32_t)((w >> (2 * (L - k))) & ((1ull << (2 * k)) - 1));
+            const SeedEntry e = seed[sidx];
+            sp = e.cnt ? e.sp : 1u;
+            ep = e.cnt ? e.sp + e.cnt - 1u : 0u;
+            if (TALLY) t_probe++;
+          } else {
+            const uint32_t c = (uint32_t)(w >> (2 * (L - 1))) & 3u;
+            sp = c == 0 ? cA : (c == 1 ? cC : (c == 2 ? cG : cT));
+            ep = (c == 0 ? cC : (c == 1 ? cG : (c == 2 ? cN : cEnd))) - 1;
+          }
+          i = L - k;
+          steps_done = 0;
+          fresh = false;
         } else {
-          const uint32_t c = (uint32_t)(w >> (2 * (L - 1))) & 3u;
-          sp = c == 0 ? cA : (c == 1 ? cC : (c == 2 ? cG : cT));
-          ep = (c == 0 ? cC : (c == 1 ? cG : (c == 2 ? cN : cEnd))) - 1;
+          i--;
+          const uint32_t c = (uint32_t)(w >> (2 * i)) & 3u;
+          const uint32_t cl = c == 0 ? cA : (c == 1 ? cC : (c == 2 ? cG : cT));
+          if (TALLY) { t_step++; t_blk += ((sp - 1) >> 8) == (ep >> 8) ? 1u : 2u; }
+          quad_step(blocks, cl, sp, ep, c, l);
+          steps_done++;
         }
-        i = L - k;
-        fresh = false;
+        if (sp > ep || i == 0) {
+          finished = true;
+          out_count = sp > ep ? 0ull : (uint64_t)(ep - sp) + 1ull;
+        } else if (VERIFY) {
+          const uint32_t cnt = ep - sp + 1u;
+          if (cnt <= 8u && (int)(3u * cnt) <= i && steps_done >= verify_after) { mode = 1; vj = 0; vhits = 0; }
+        }
+      } else if (mode == 1) {
+        vp = ix.dense_sa[sp + (uint32_t)vj];
+        if (TALLY) t_vsa++;
+        if (vp >= (uint32_t)i) mode = 2;
+        else vj++;
       } else {
-        i--;
-        const uint32_t c = (uint32_t)(w >> (2 * i)) & 3u;
-        const uint32_t cl = c == 0 ? cA : (c == 1 ? cC : (c == 2 ? cG : cT));
-        if (TALLY) { t_step++; t_blk += ((sp - 1) >> 8) == (ep >> 8) ? 1u : 2u; }
-        quad_step(blocks, cl, sp, ep, c, l);
+        const uint32_t bad = quad_sum(verify_part(ix.text4, (uint64_t)vp - (uint64_t)i, i, 0, l, w));
+        if (TALLY) t_vtxt++;
+        if (!bad) vhits++;
+        vj++;
+        mode = 1;
       }
-      if (sp > ep || i == 0) {
-        if (l == t) res = sp > ep ? 0ull : (uint64_t)(ep - sp) + 1ull;
+      if (VERIFY && mode == 1 && vj > (int)(ep - sp)) { finished = true; out_count = vhits; }
+      if (finished) {
+        if (l == t) res = out_count;
         t++;
         fresh = true;
+        mode = 0;
         if (t == nvalid) {  // group finished: one 32-B store, then the next group
           if (l < nvalid) counts[4 * m + l] = res;
           m += nquads;
@@ -519,6 +580,10 @@ __global__ __launch_bounds__(256) void count_nt2_quad4_kernel(DevIndex ix, const
     atomicAdd(&tally[0], (unsigned long long)t_probe);
     atomicAdd(&tally[1], (unsigned long long)t_step);
     atomicAdd(&tally[2], (unsigned long long)t_blk);
+    if (VERIFY) {
+      atomicAdd(&tally[3], (unsigned long long)t_vsa);
+      atomicAdd(&tally[4], (unsigned long long)t_vtxt);
+    }
   }
 }
 
@@ -662,36 +727,6 @@ __global__ __launch_bounds__(256) void pack_nt2_kernel(const uint8_t* __restrict
     }
     if (!ok) atomicAdd(bad, 1ull);
   }
-}
-
-// 16 packed 2-bit letters (low 32 bits of x) -> 16 nibbles holding the same letters
-__device__ __forceinline__ uint64_t spread_letters16(uint64_t x) {
-  x &= 0xFFFFFFFFull;
-  x = (x | (x << 16)) & 0x0000FFFF0000FFFFull;
-  x = (x | (x << 8)) & 0x00FF00FF00FF00FFull;
-  x = (x | (x << 4)) & 0x0F0F0F0F0F0F0F0Full;
-  x = (x | (x << 2)) & 0x3333333333333333ull;
-  return x;
-}
-
-struct Text20 { uint32_t w[5]; };  // 5 consecutive u32 of the 4-bit text: any 32 symbols at any nibble offset
-
-// Does text[g + 32 j0' .. ) equal this lane's 32-letter query word?  Lane l of the quad compares window symbols
-// [128 c + 32 l, +32) of a window of `len` symbols starting at text position g; returns 1 on a mismatch.
-__device__ __forceinline__ uint32_t verify_part(const uint32_t* __restrict__ text4, uint64_t g, int len, int c, int l, uint64_t qword) {
-  const int j0 = 128 * c + 32 * l;
-  const int m = len - j0 < 0 ? 0 : (len - j0 > 32 ? 32 : len - j0);  // symbols this lane checks
-  if (m == 0) return 0u;
-  const uint64_t t0 = g + (uint64_t)j0;
-  const Text20 t = *reinterpret_cast<const Text20*>(text4 + (t0 >> 3));
-  const int sh = 4 * (int)(t0 & 7);
-  const uint64_t a0 = (uint64_t)t.w[0] | ((uint64_t)t.w[1] << 32), a1 = (uint64_t)t.w[2] | ((uint64_t)t.w[3] << 32), a2 = t.w[4];
-  const uint64_t lo = sh ? (a0 >> sh) | (a1 << (64 - sh)) : a0;
-  const uint64_t hi = sh ? (a1 >> sh) | (a2 << (64 - sh)) : a1;
-  const uint64_t qlo = spread_letters16(qword), qhi = spread_letters16(qword >> 32);
-  const uint64_t mlo = m >= 16 ? ~0ull : ((1ull << (4 * m)) - 1);
-  const uint64_t mhi = m <= 16 ? 0ull : (m >= 32 ? ~0ull : ((1ull << (4 * (m - 16))) - 1));
-  return (((lo ^ qlo) & mlo) | ((hi ^ qhi) & mhi)) ? 1u : 0u;
 }
 
 // Packed reads of any length (W = ceil(L/32) words per query, letter j in word j/32, bits 2(j%32)): the quad design

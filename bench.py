@@ -200,7 +200,7 @@ def main():
     n_batches = max(1, min(K + W, 8))
     batches = [torch.randint(0, 1 << (2 * L), (nq,), dtype=torch.int64, device=dev, generator=gen) for _ in range(n_batches)]
     counts = torch.zeros(nq, dtype=torch.int64, device=dev)
-    tally = torch.zeros(3, dtype=torch.int64, device=dev)
+    tally = torch.zeros(5, dtype=torch.int64, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
 
     def step(i, seeded=True):
@@ -238,7 +238,7 @@ def main():
     for i in range(K):
         ix.dev_count_nt2_tally(batches[(W + i) % n_batches].data_ptr(), nq, L, counts.data_ptr(), tally.data_ptr(), True, stream, 0)
     torch.cuda.synchronize()
-    probes, steps_exec, blocks = [int(x) / K for x in tally.cpu().tolist()]
+    probes, steps_exec, blocks = [int(x) / K for x in tally.cpu().tolist()[:3]]
     alg_bytes = 16.0 * probes + 104.0 * blocks + nq * (8.0 + 8.0)  # probe 16 B, block 104 B, query 8 B, result 8 B
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
@@ -297,7 +297,7 @@ def main():
             for i in range(5):
                 ix.dev_count_nt2_tally(batches[i % n_batches].data_ptr(), nq, L, counts.data_ptr(), tally.data_ptr(), False, stream, 0)
             torch.cuda.synchronize()
-            p2, s2, b2 = [int(x) / 5 for x in tally.cpu().tolist()]
+            p2, s2, b2 = [int(x) / 5 for x in tally.cpu().tolist()[:3]]
             ab = 104.0 * b2 + nq * 16.0
             extra["unseeded"] = {"queries_per_s": nq / (ms * 1e-3), "kernel_ms": ms, "achieved_GBs": ab / (ms * 1e-3) / 1e9,
                                  "frac": ab / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "steps_per_query": s2 / nq, "block_reads_per_query": b2 / nq}
@@ -322,11 +322,33 @@ def main():
             tally.zero_()
             ix.dev_count_nt2_tally(d_words.data_ptr(), ns, L, counts.data_ptr(), tally.data_ptr(), True, stream, 0)
             torch.cuda.synchronize()
-            p3, s3, b3 = [int(x) for x in tally.cpu().tolist()]
+            p3, s3, b3 = [int(x) for x in tally.cpu().tolist()[:3]]
             ab = 16.0 * p3 + 104.0 * b3 + ns * 16.0
             extra["present_queries"] = {"queries": ns, "queries_per_s": ns / (ms * 1e-3), "kernel_ms": ms,
                                         "achieved_GBs": ab / (ms * 1e-3) / 1e9, "frac": ab / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                         "steps_per_query": s3 / ns}
+            # the same present k-mers with seed-and-verify (dense SA + 4-bit text resident in HBM)
+            want_present = counts[:ns].clone()
+            ix.set_verify(2)
+            for _ in range(2):
+                ix.dev_count_nt2(d_words.data_ptr(), ns, L, counts.data_ptr(), True, stream, 0)
+            e0.record()
+            for _ in range(5):
+                ix.dev_count_nt2(d_words.data_ptr(), ns, L, counts.data_ptr(), True, stream, 0)
+            e1.record()
+            torch.cuda.synchronize()
+            msv = e0.elapsed_time(e1) / 5
+            assert bool(torch.equal(counts[:ns], want_present)), "seed-and-verify changed a count"
+            ix.dev_count_nt2(batches[0].data_ptr(), nq, L, counts.data_ptr(), True, stream, 0)  # random batch under verify
+            e0.record()
+            for i in range(5):
+                ix.dev_count_nt2(batches[i % n_batches].data_ptr(), nq, L, counts.data_ptr(), True, stream, 0)
+            e1.record()
+            torch.cuda.synchronize()
+            extra["seed_and_verify"] = {"present_queries_per_s": ns / (msv * 1e-3), "present_kernel_ms": msv,
+                                        "random_queries_per_s": nq / (e0.elapsed_time(e1) / 5 * 1e-3), "identical_counts": True}
+            ix.set_verify(-1)
+            ix.set_locate_sa_ratio(0)
             # ASCII boundary with on-device packing in the timed region (31 B/query read instead of 8 B)
             na = min(nq, 5_000_000)
             asc = torch.from_numpy(unpack_nt2(batches[0][:na].cpu().numpy().view(np.uint64), L).reshape(-1)).to(dev)

@@ -151,8 +151,9 @@ int awry_dev_pack_nt2(awry_index_t *idx, int slot, const void *d_ascii, uint64_t
 /* the hot kernel: count n packed k-mers -> u64 counts.  use_seed != 0 starts from the seed table */
 int awry_dev_count_nt2(awry_index_t *idx, int slot, const void *d_words, uint64_t n, int L, void *d_counts,
                        int use_seed, void *stream);
-/* same kernel with a work census for the roofline figure: d_tally[3] (u64, caller-zeroed) += {seed probes,
- * executed steps, distinct BWT blocks ranked} -- the tallies SURVEY.md 8(d) prices at 16 B / 104 B each */
+/* same kernel with a work census for the roofline figure: d_tally[5] (u64, caller-zeroed) += {seed probes,
+ * executed steps, distinct BWT blocks ranked, SA reads and text windows of seed-and-verify} -- the first three are
+ * the tallies SURVEY.md 8(d) prices at 16 B / 104 B each */
 int awry_dev_count_nt2_tally(awry_index_t *idx, int slot, const void *d_words, uint64_t n, int L, void *d_counts,
                              int use_seed, void *d_tally, void *stream);
 /* generic path: ASCII queries + u64 offsets[n+1] -> counts[n], optional ranges[2n] (start,end) and status[n] bytes */

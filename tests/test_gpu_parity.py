@@ -362,3 +362,24 @@ def test_seed_and_verify_does_not_change_results(oracle, L, after):
     ix.set_locate_sa_ratio(4)  # leaving ratio 1 switches verify off again
     assert not ix.verify_enabled()
     assert all(np.array_equal(x, y) for x, y in zip(ix.locate_reads_nt2(q2d), (ooff, ogpos, opos)))
+
+
+def test_seed_and_verify_in_the_kmer_kernel(oracle):
+    """the packed k-mer kernel (L <= 32) with awry_set_verify on: same counts as the oracle for every length / seed k"""
+    text, st, hd = repeat_text(9)
+    ix = gpu_index(text, 0, 8, 0, st, hd)
+    oi = oracle.OracleIndex.from_text(text, 0, 8, 0, st, hd)
+    for L in (9, 16, 24, 31, 32):
+        rng = np.random.default_rng(L)
+        starts = np.concatenate([rng.integers(0, len(text) - L - 1, size=2000), [0, 1, 2, 3]])
+        reads = text[starts[:, None] + np.arange(L)[None, :]]
+        reads = reads[~((reads == ord("N")) | (reads == ord("$"))).any(axis=1)]
+        q2d = np.concatenate([reads, synth.random_queries(1001, L, 0, L)])
+        want, _ = oi.parallel_count(*synth.fixed_to_csr(q2d), 4)
+        for after in (0, 1, 3):
+            ix.set_verify(after)
+            for k in (-1, 3, 8):
+                ix.set_seed_kmer_len(k)
+                assert np.array_equal(ix.count_kmers_nt2(q2d, True), want), (L, after, k)
+            assert np.array_equal(ix.count_kmers_nt2(q2d, False), want), (L, after)
+        ix.set_verify(-1)

@@ -590,9 +590,34 @@ void locate_shard(Replica& r, const uint8_t* qbytes, const uint64_t* qoff, Shard
   ChunkBuffers cb;
   DevBuf<uint64_t> hit_off, scratch, d_gpos, d_pos;
   out.hit_counts.resize(sh.hi - sh.lo);
+  DevBuf<uint64_t> words, rstart;
+  DevBuf<unsigned long long> bad;
+  static const bool no_fast = getenv("AWRY_HOST_PATH") && !strcmp(getenv("AWRY_HOST_PATH"), "generic");
   for (Shard c : chunk_queries(qoff, sh.lo, sh.hi)) {
     const uint64_t n = c.hi - c.lo;
-    run_count_chunk(r, cb, qbytes, qoff, c, true);
+    // fixed-length ACGT reads take the packed quad kernel (seed table, seed-and-verify when enabled); a chunk holding
+    // any other byte is redone by the generic kernel, so the result never depends on the path taken
+    uint64_t L = 0;
+    bool packed = !no_fast && r.dev.alphabet == NUCLEOTIDE && r.dev.bwt_len < (1ull << 32) - 512 && shard_fixed_length(qoff, c, L);
+    if (packed) {
+      const uint64_t W = (L + 31) / 32, nbytes = n * L;
+      if (cb.q.n < nbytes + 16) cb.q.alloc(nbytes + 16);
+      if (words.n < n * W) words.alloc(n * W);
+      if (rstart.n < n) rstart.alloc(n);
+      if (cb.counts.n < n) cb.counts.alloc(n);
+      if (!bad.p) bad.alloc(1);
+      HIP_CHECK(hipMemcpyAsync(cb.q.p, qbytes + qoff[c.lo], nbytes, hipMemcpyHostToDevice, r.stream));
+      HIP_CHECK(hipMemsetAsync(bad.p, 0, 8, r.stream));
+      hipLaunchKernelGGL(pack_nt2_kernel, dim3(grid_for(r, n, 256)), dim3(256), 0, r.stream, cb.q.p, n, (int)L, words.p, bad.p);
+      HIP_CHECK(hipGetLastError());
+      launch_count_nt2_long(r, words.p, n, (int)L, cb.counts.p, rstart.p, true, r.stream);
+      unsigned long long h_bad = 0;
+      HIP_CHECK(hipMemcpyAsync(&h_bad, bad.p, 8, hipMemcpyDeviceToHost, r.stream));
+      HIP_CHECK(hipStreamSynchronize(r.stream));
+      packed = h_bad == 0;
+      cb.h_status.clear();
+    }
+    if (!packed) run_count_chunk(r, cb, qbytes, qoff, c, true);
     if (hit_off.n < n + 1) hit_off.alloc(n + 1);
     const uint64_t sb = scan_tiles(n) + 1;
     if (scratch.n < sb) scratch.alloc(sb);
@@ -605,7 +630,8 @@ void locate_shard(Replica& r, const uint8_t* qbytes, const uint64_t* qoff, Shard
     if (total == 0) continue;
     if (d_gpos.n < total) d_gpos.alloc(total);
     if (d_pos.n < 2 * total) d_pos.alloc(2 * total);
-    launch_locate(r, cb.ranges.p, 2, hit_off.p, n, total, d_gpos.p, d_pos.p, r.stream);
+    if (packed) launch_locate(r, rstart.p, 1, hit_off.p, n, total, d_gpos.p, d_pos.p, r.stream);
+    else launch_locate(r, cb.ranges.p, 2, hit_off.p, n, total, d_gpos.p, d_pos.p, r.stream);
     const size_t at = out.pos.size();
     out.pos.resize(at + total);
     HIP_CHECK(hipMemcpyAsync(out.pos.data() + at, d_pos.p, total * 16, hipMemcpyDeviceToHost, r.stream));

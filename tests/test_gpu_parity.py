@@ -383,3 +383,25 @@ def test_seed_and_verify_in_the_kmer_kernel(oracle):
                 assert np.array_equal(ix.count_kmers_nt2(q2d, True), want), (L, after, k)
             assert np.array_equal(ix.count_kmers_nt2(q2d, False), want), (L, after)
         ix.set_verify(-1)
+
+
+@pytest.mark.parametrize("L,verify", [(31, -1), (101, -1), (101, 2), (150, 0)])
+def test_host_locate_fast_path_equals_oracle(oracle, L, verify):
+    """parallel_locate on fixed-length read batches takes the packed kernels (and seed-and-verify when enabled);
+    a batch with N / lower-case / IUPAC bytes is redone by the generic kernel.  Same CSR as the oracle either way."""
+    text, st, hd = repeat_text(21)
+    ix = gpu_index(text, 0, 8, 0, st, hd)
+    oi = oracle.OracleIndex.from_text(text, 0, 8, 0, st, hd)
+    ix.set_verify(verify)
+    rng = np.random.default_rng(L)
+    starts = rng.integers(0, len(text) - L - 1, size=2500)
+    reads = text[starts[:, None] + np.arange(L)[None, :]]
+    reads = reads[~((reads == ord("N")) | (reads == ord("$"))).any(axis=1)]
+    clean = np.concatenate([reads, synth.random_queries(300, L, 0, 2)])
+    dirty = clean.copy()
+    dirty[3, 5] = ord("N"); dirty[9] = np.frombuffer(bytes(dirty[9]).lower(), np.uint8); dirty[77, 0] = ord("Y")
+    for q2d in (clean, dirty):
+        qb, qo = synth.fixed_to_csr(q2d)
+        want = oi.parallel_locate(qb, qo, 4)[:3]
+        got = ix.parallel_locate_csr(qb, qo)
+        assert all(np.array_equal(x, y) for x, y in zip(got, want))

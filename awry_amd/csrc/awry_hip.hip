@@ -181,6 +181,7 @@ void build_seed(awry_index* ix, Replica& r, int k) {
     hipLaunchKernelGGL(seed_extend_kernel, dim3(grid_for(r, nchild * 4, 256)), dim3(256), 0, r.stream, r.dev, cur, nxt, nchild);
     cur = nxt;
   }
+  hipLaunchKernelGGL(seed_finalize_kernel, dim3(grid_for(r, nfinal, 256)), dim3(256), 0, r.stream, r.dev, a.p, nfinal);
   HIP_CHECK(hipGetLastError());
   HIP_CHECK(hipStreamSynchronize(r.stream));
   r.seed = std::move(a);

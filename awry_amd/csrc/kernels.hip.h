@@ -147,10 +147,14 @@ __global__ __launch_bounds__(256) void count_scalar_kernel(DevIndex ix, const ui
         }
         if (acgt) {
           const SeedEntry se = ix.seed[sidx];
-          sp = se.cnt ? se.sp : 1;
-          ep = se.cnt ? (uint64_t)se.sp + se.cnt - 1 : 0;
-          i = e - k;
-          seeded = true;
+          const uint32_t scnt = seed_cnt(se);
+          if (scnt != SEED_CNT_SAT) {
+            sp = scnt ? se.sp : 1;
+            ep = scnt ? (uint64_t)se.sp + scnt - 1 : 0;
+            i = e - k;
+            seeded = true;
+            if (scnt == 1 && i > b && seed_sym(se) != (int)lut[ascii[i - 1]]) { sp = 1; ep = 0; }  // BWT[sp] is not the next symbol
+          }
         }
       }
       if (!seeded) {
@@ -417,15 +421,23 @@ __global__ __launch_bounds__(256) void count_nt2_quad_kernel(DevIndex ix, const 
         if (USE_SEED) {
           const uint32_t sidx = (uint32_t)((w >> (2 * (L - k))) & ((1ull << (2 * k)) - 1));
           const SeedEntry e = seed[sidx];
-          sp = e.cnt ? e.sp : 1u;
-          ep = e.cnt ? e.sp + e.cnt - 1u : 0u;
+          const uint32_t scnt = seed_cnt(e);
+          sp = scnt ? e.sp : 1u;
+          ep = scnt ? e.sp + scnt - 1u : 0u;
+          i = L - k;
+          if (scnt == 1u && i > 0) {  // singleton: it survives the next step only if BWT[sp] is the next letter
+            const uint32_t nc = (uint32_t)(w >> (2 * (i - 1))) & 3u;
+            if (seed_sym(e) != (int)(nc == 3u ? 5u : nc + 1u)) { sp = 1u; ep = 0u; }
+          }
+          if (scnt == SEED_CNT_SAT) i = -1;  // count not representable: start this query without the table
           if (TALLY) t_probe++;
-        } else {
+        }
+        if (!USE_SEED || i < 0) {
           const uint32_t c = (uint32_t)(w >> (2 * (L - 1))) & 3u;  // SearchRange::new(last symbol)
           sp = c == 0 ? cA : (c == 1 ? cC : (c == 2 ? cG : cT));
           ep = (c == 0 ? cC : (c == 1 ? cG : (c == 2 ? cN : cEnd))) - 1;
+          i = L - 1;
         }
-        i = L - k;
         fresh = false;
       } else {
         i--;
@@ -521,15 +533,23 @@ __global__ __launch_bounds__(256) void count_nt2_quad4_kernel(DevIndex ix, const
           if (USE_SEED) {
             const uint32_t sidx = (uint32_t)((w >> (2 * (L - k))) & ((1ull << (2 * k)) - 1));
             const SeedEntry e = seed[sidx];
-            sp = e.cnt ? e.sp : 1u;
-            ep = e.cnt ? e.sp + e.cnt - 1u : 0u;
+            const uint32_t scnt = seed_cnt(e);
+            sp = scnt ? e.sp : 1u;
+            ep = scnt ? e.sp + scnt - 1u : 0u;
+            i = L - k;
+            if (scnt == 1u && i > 0) {  // singleton: it survives the next step only if BWT[sp] is the next letter
+              const uint32_t nc = (uint32_t)(w >> (2 * (i - 1))) & 3u;
+              if (seed_sym(e) != (int)(nc == 3u ? 5u : nc + 1u)) { sp = 1u; ep = 0u; }
+            }
+            if (scnt == SEED_CNT_SAT) i = -1;  // count not representable: start this query without the table
             if (TALLY) t_probe++;
-          } else {
+          }
+          if (!USE_SEED || i < 0) {
             const uint32_t c = (uint32_t)(w >> (2 * (L - 1))) & 3u;
             sp = c == 0 ? cA : (c == 1 ? cC : (c == 2 ? cG : cT));
             ep = (c == 0 ? cC : (c == 1 ? cG : (c == 2 ? cN : cEnd))) - 1;
+            i = L - 1;
           }
-          i = L - k;
           steps_done = 0;
           fresh = false;
         } else {
@@ -641,15 +661,23 @@ __global__ __launch_bounds__(256) void count_nt2_chunk_kernel(DevIndex ix, const
           if (USE_SEED) {
             const uint32_t sidx = (uint32_t)((w >> (2 * (L - k))) & ((1ull << (2 * k)) - 1));
             const SeedEntry e = seed[sidx];
-            sp = e.cnt ? e.sp : 1u;
-            ep = e.cnt ? e.sp + e.cnt - 1u : 0u;
+            const uint32_t scnt = seed_cnt(e);
+            sp = scnt ? e.sp : 1u;
+            ep = scnt ? e.sp + scnt - 1u : 0u;
+            i = L - k;
+            if (scnt == 1u && i > 0) {
+              const uint32_t nc = (uint32_t)(w >> (2 * (i - 1))) & 3u;
+              if (seed_sym(e) != (int)(nc == 3u ? 5u : nc + 1u)) { sp = 1u; ep = 0u; }
+            }
+            if (scnt == SEED_CNT_SAT) i = -1;
             if (TALLY) t_probe++;
-          } else {
+          }
+          if (!USE_SEED || i < 0) {
             const uint32_t ch = (uint32_t)(w >> (2 * (L - 1))) & 3u;  // SearchRange::new(last symbol)
             sp = ch == 0 ? cA : (ch == 1 ? cC : (ch == 2 ? cG : cT));
             ep = (ch == 0 ? cC : (ch == 1 ? cG : (ch == 2 ? cN : cEnd))) - 1;
+            i = L - 1;
           }
-          i = L - k;
           fresh = false;
         } else {
           i--;
@@ -705,6 +733,19 @@ __global__ __launch_bounds__(256) void seed_extend_kernel(DevIndex ix, const See
       r.cnt = sp > ep ? 0u : ep - sp + 1u;
     }
     if (l == 0) child[o] = r;
+  }
+}
+
+// last pass over the finished table: pack the BWT symbol of singleton ranges and saturate oversized counts
+// (intermediate levels keep plain 32-bit counts because a child is derived from its parent's exact range)
+__global__ __launch_bounds__(256) void seed_finalize_kernel(DevIndex ix, SeedEntry* __restrict__ table, uint64_t nentries) {
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t o = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; o < nentries; o += stride) {
+    SeedEntry e = table[o];
+    if (e.cnt == 1u) e.cnt = 1u | ((uint32_t)symbol_at<NUCLEOTIDE>(ix, e.sp) << 29);
+    else if (e.cnt >= SEED_CNT_SAT) e.cnt = SEED_CNT_SAT;
+    else continue;
+    table[o] = e;
   }
 }
 
@@ -770,18 +811,27 @@ __global__ __launch_bounds__(256) void count_nt2_reads_kernel(DevIndex ix, const
           const int a = first >> 5, sh = 2 * (first & 31);
           uint64_t win = qw[a] >> sh;
           if (sh && a + 1 < W) win |= qw[a + 1] << (64 - sh);
+          SeedEntry e{1u, 0u};
+          uint32_t scnt = SEED_CNT_SAT;
           if (USE_SEED) {
-            const SeedEntry e = seed[(uint32_t)(win & ((1ull << (2 * k)) - 1))];
-            sp = e.cnt ? e.sp : 1u;
-            ep = e.cnt ? e.sp + e.cnt - 1u : 0u;
-          } else {
-            const uint32_t c = (uint32_t)win & 3u;  // k == 1: the window is the last letter
+            e = seed[(uint32_t)(win & ((1ull << (2 * k)) - 1))];
+            scnt = seed_cnt(e);
+            sp = scnt ? e.sp : 1u;
+            ep = scnt ? e.sp + scnt - 1u : 0u;
+            i = first;
+          }
+          if (!USE_SEED || scnt == SEED_CNT_SAT) {  // no table, or a count the entry cannot represent
+            const uint32_t c = (uint32_t)(qw[(L - 1) >> 5] >> (2 * ((L - 1) & 31))) & 3u;  // SearchRange::new(last letter)
             sp = c == 0 ? cA : (c == 1 ? cC : (c == 2 ? cG : cT));
             ep = (c == 0 ? cC : (c == 1 ? cG : (c == 2 ? cN : cEnd))) - 1;
+            i = L - 1;
           }
-          i = first;
           steps_done = 0;
           w = i > 0 ? qw[(i - 1) >> 5] : 0;
+          if (USE_SEED && scnt == 1u && i > 0) {  // singleton: it survives the next step only if BWT[sp] is the next letter
+            const uint32_t nc = (uint32_t)(w >> (2 * ((i - 1) & 31))) & 3u;
+            if (seed_sym(e) != (int)(nc == 3u ? 5u : nc + 1u)) { sp = 1u; ep = 0u; }
+          }
           fresh = false;
         } else {
           i--;

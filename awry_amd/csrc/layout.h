@@ -62,8 +62,15 @@ AWRY_HD int aa_ms_half(int t) { return (t % 6) & 1; }
 AWRY_HD int nt_letter_of_index(int idx) { return idx == 5 ? 3 : (idx >= 1 && idx <= 3 ? idx - 1 : -1); }
 AWRY_HD int nt_index_of_letter(int l) { return l == 3 ? 5 : l + 1; }
 
-// seed-table entry: the search range of a k-mer as (start row, row count); count 0 = absent
+// seed-table entry: the search range of a k-mer as (start row, row count); count 0 = absent.
+// Final-level entries pack two things into `cnt`: bits 0..28 the count, saturating at SEED_CNT_SAT ("at least
+// this many: ignore the table for this query"), and -- for singleton ranges only -- bits 29..31 the symbol index
+// stored in the BWT at row sp.  A singleton range survives a step with symbol c iff BWT[sp] == c, so most absent
+// k-mers are rejected by the entry itself, without touching a BWT block.
 struct SeedEntry { uint32_t sp, cnt; };
+constexpr uint32_t SEED_CNT_SAT = 0x1FFFFFFFu;
+AWRY_HD uint32_t seed_cnt(SeedEntry e) { return e.cnt & SEED_CNT_SAT; }
+AWRY_HD int seed_sym(SeedEntry e) { return (int)(e.cnt >> 29); }
 
 // Everything a kernel needs, passed by value (fits the kernarg segment).
 struct DevIndex {

@@ -405,3 +405,24 @@ def test_host_locate_fast_path_equals_oracle(oracle, L, verify):
         want = oi.parallel_locate(qb, qo, 4)[:3]
         got = ix.parallel_locate_csr(qb, qo)
         assert all(np.array_equal(x, y) for x, y in zip(got, want))
+
+
+def test_seed_entry_count_saturation_falls_back():
+    """a k-mer with >= 2^29 occurrences cannot be represented in a seed entry: the kernels must ignore the table
+    for such queries.  Text = 6e8 x 'A' + a short tail; counts are known in closed form."""
+    n_a = 600_000_000
+    tail = b"CGTACGTTAGC"
+    text = np.concatenate([np.full(n_a, ord("A"), np.uint8), np.frombuffer(tail + b"$", np.uint8)])
+    ix = FmIndex.from_text(text, 0, 64, 0, build_device=0).set_devices([0])
+    ix.set_seed_kmer_len(8)
+    qs = {b"A" * 31: n_a - 30, b"A" * 9: n_a - 8, b"A" * 8: n_a - 7, b"A" * 20 + b"CGTACGTTAGC": 1, b"A" * 30 + b"C": 1,
+          b"A" * 30 + b"G": 0, b"CGTACGTTAGC" + b"A" * 20: 0, b"A" * 12 + b"C" + b"A" * 18: 0}
+    for L in (31, 9, 8):
+        batch = [q for q in qs if len(q) == L]
+        q2d = np.frombuffer(b"".join(batch), np.uint8).reshape(len(batch), L)
+        want = np.array([qs[q] for q in batch], dtype=np.uint64)
+        assert np.array_equal(ix.count_kmers_nt2(q2d, True), want)
+        assert np.array_equal(ix.count_kmers_nt2(q2d, False), want)
+        assert np.array_equal(ix.parallel_count_csr(*synth.fixed_to_csr(q2d)), want)
+    ragged = [b"A" * 40, b"A" * 31 + b"C", b"AAC", b"A" * 33 + b"CGTACGTTAGC"]
+    assert ix.parallel_count(ragged).tolist() == [n_a - 39, 1, 1, 1]

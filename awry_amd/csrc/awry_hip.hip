@@ -308,7 +308,6 @@ void build_dense_sa(awry_index* ix, Replica& r, int ratio) {
   r.dev.dense_ratio = 0;
   if (ratio <= 0) return;
   require(ix->host.bwt_len < (1ull << 32), "a dense device SA needs bwt_len < 2^32");
-  if ((uint64_t)ratio >= ix->host.sa_ratio && ix->host.sa_ratio % (uint64_t)ratio == 0 && (uint64_t)ratio == ix->host.sa_ratio) return;
   const uint64_t nentries = (ix->host.bwt_len + ratio - 1) / ratio;
   DevBuf<uint32_t> d(nentries);
   const dim3 g(grid_for(r, nentries, 256)), b(256);
@@ -331,6 +330,7 @@ void build_verify(awry_index* ix, Replica& r, int after_steps) {
   if (after_steps < 0) return;
   require(ix->host.alphabet == NUCLEOTIDE && narrow(ix->host), "seed-and-verify needs a nucleotide index with bwt_len < 2^32");
   if (r.dense_ratio != 1) build_dense_sa(ix, r, 1);
+  if (r.dense_ratio != 1 || !r.dense_sa.p) throw HipError("seed-and-verify: the ratio-1 dense SA is missing");
   const uint64_t nwords = (ix->host.bwt_len + 7) / 8 + 8;  // + slack: a 32-symbol window read touches 5 words
   DevBuf<uint32_t> t(nwords);
   HIP_CHECK(hipMemsetAsync(t.p, 0, nwords * 4, r.stream));

@@ -511,8 +511,15 @@ __global__ __launch_bounds__(256) void count_nt2_quad4_kernel(DevIndex ix, const
   const int verify_after = (int)ix.verify_after;
   const uint32_t cA = (uint32_t)ix.prefix_sums[1], cC = (uint32_t)ix.prefix_sums[2], cG = (uint32_t)ix.prefix_sums[3],
                  cN = (uint32_t)ix.prefix_sums[4], cT = (uint32_t)ix.prefix_sums[5], cEnd = (uint32_t)ix.prefix_sums[6];
+  const int kshift = 2 * (L - k);
+  const uint64_t kmask = (1ull << (2 * k)) - 1;
   bool have = m < ngroups;
   uint64_t wq = (have && 4 * m + l < n) ? queries[4 * m + l] : 0;  // this lane's query of the group
+  // the four seed probes of a group are issued together, one per lane, as soon as the group's words are there;
+  // the next group's words are fetched one group ahead.  A query that the entry alone decides costs no wait.
+  uint64_t eq = 0;        // this lane's seed entry (sp | cnt << 32)
+  if (USE_SEED && have) { const SeedEntry e0 = seed[(uint32_t)((wq >> kshift) & kmask)]; eq = (uint64_t)e0.sp | ((uint64_t)e0.cnt << 32); }
+  uint64_t wq_next = (m + nquads < ngroups && 4 * (m + nquads) + l < n) ? queries[4 * (m + nquads) + l] : 0;
   int nvalid = have ? (int)(n - 4 * m < 4 ? n - 4 * m : 4) : 0;
   int t = 0;              // query of the group being searched
   bool fresh = true;
@@ -531,8 +538,8 @@ __global__ __launch_bounds__(256) void count_nt2_quad4_kernel(DevIndex ix, const
         if (fresh) {
           w = __shfl(wq, (lane & ~3) | t, 64);
           if (USE_SEED) {
-            const uint32_t sidx = (uint32_t)((w >> (2 * (L - k))) & ((1ull << (2 * k)) - 1));
-            const SeedEntry e = seed[sidx];
+            const uint64_t ev = __shfl(eq, (lane & ~3) | t, 64);
+            const SeedEntry e{(uint32_t)ev, (uint32_t)(ev >> 32)};
             const uint32_t scnt = seed_cnt(e);
             sp = scnt ? e.sp : 1u;
             ep = scnt ? e.sp + scnt - 1u : 0u;
@@ -591,7 +598,9 @@ __global__ __launch_bounds__(256) void count_nt2_quad4_kernel(DevIndex ix, const
           have = m < ngroups;
           t = 0;
           nvalid = have ? (int)(n - 4 * m < 4 ? n - 4 * m : 4) : 0;
-          wq = (have && 4 * m + l < n) ? queries[4 * m + l] : 0;
+          wq = wq_next;
+          if (USE_SEED && have) { const SeedEntry e0 = seed[(uint32_t)((wq >> kshift) & kmask)]; eq = (uint64_t)e0.sp | ((uint64_t)e0.cnt << 32); }
+          wq_next = (m + nquads < ngroups && 4 * (m + nquads) + l < n) ? queries[4 * (m + nquads) + l] : 0;
         }
       }
     }

@@ -426,3 +426,52 @@ def test_seed_entry_count_saturation_falls_back():
         assert np.array_equal(ix.parallel_count_csr(*synth.fixed_to_csr(q2d)), want)
     ragged = [b"A" * 40, b"A" * 31 + b"C", b"AAC", b"A" * 33 + b"CGTACGTTAGC"]
     assert ix.parallel_count(ragged).tolist() == [n_a - 39, 1, 1, 1]
+
+
+def test_fuzz_small_indexes_against_oracle(oracle):
+    """many small seeded indexes (both alphabets, 1..5000 symbols, 1..6 records, N/X runs, SA ratios 1..64): counts,
+    ranges and locations of mixed queries equal the oracle's; packed kernels agree where they apply"""
+    rng = np.random.default_rng(2024)
+    sizes = [1, 2, 3, 7, 31, 100, 255, 256, 257, 1000, 5000]
+    for trial in range(44):
+        alphabet = trial % 2
+        n = sizes[trial % len(sizes)]
+        recs = int(min(max(1, n // 3), rng.integers(1, 7)))
+        nfrac = float(rng.choice([0.0, 0.1, 0.4]))
+        ratio = int(rng.choice([1, 2, 8, 64]))
+        text, st, hd = synth.make_text(n, alphabet, 7000 + trial, recs if n >= 7 else 1, nfrac)
+        ix = gpu_index(text, alphabet, ratio, 0, st, hd)
+        oi = oracle.OracleIndex.from_text(text, alphabet, ratio, 0, st, hd)
+        letters = b"ACGTN" if alphabet == 0 else b"ACDEFGHIKLMNPQRSTVWYX"
+        qs = []
+        for _ in range(60):
+            L = int(rng.integers(1, min(40, n + 3) + 1))
+            if rng.random() < 0.5 and n >= L:
+                p = int(rng.integers(0, n - L + 1))
+                q = bytes(text[p:p + L])
+            else:
+                q = bytes(rng.choice(np.frombuffer(letters, np.uint8), size=L))
+            if b"$" in q:
+                continue
+            qs.append(q.lower() if rng.random() < 0.1 else q)
+        qb, qo = __import__("awry_amd").fm_index.pack_queries(qs)
+        want_c, _ = oi.parallel_count(qb, qo, 2)
+        assert np.array_equal(ix.parallel_count_csr(qb, qo), want_c), trial
+        woff, wg, wp, _ = oi.parallel_locate(qb, qo, 2)
+        off, g, p = ix.parallel_locate_csr(qb, qo)
+        assert np.array_equal(off, woff) and np.array_equal(g, wg) and np.array_equal(p, wp), trial
+        if alphabet == 0 and n >= 4:
+            for L in (1, 3, min(12, n)):
+                q2d = np.concatenate([synth.sampled_queries(text, 40, L, trial, False, 0) if n > L else synth.random_queries(40, L, 0, trial),
+                                      synth.random_queries(40, L, 0, trial + 1)])
+                q2d = q2d[~((q2d == ord("N")) | (q2d == ord("$"))).any(axis=1)]
+                if len(q2d) == 0:
+                    continue
+                want, _ = oi.parallel_count(*synth.fixed_to_csr(q2d), 2)
+                for verify in (-1, 0):
+                    ix.set_verify(verify)
+                    assert np.array_equal(ix.count_kmers_nt2(q2d, True), want), (trial, L, verify)
+                    got = ix.locate_reads_nt2(q2d)
+                    wl = oi.parallel_locate(*synth.fixed_to_csr(q2d), 2)[:3]
+                    assert all(np.array_equal(x, y) for x, y in zip(got, wl)), (trial, L, verify)
+                ix.set_verify(-1)

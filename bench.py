@@ -34,6 +34,25 @@ def log(*a):
     print("[bench]", *a, file=sys.stderr, flush=True)
 
 
+def effective_cpus():
+    """CPUs this process may actually use: the cgroup CPU quota when there is one (the GPU box shows 256 logical CPUs
+    but grants 16), else the affinity mask"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            pr = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // pr))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def unpack_nt2(words, L):
     """uint64[n] packed k-mers -> uint8[n, L] ASCII (letter j in bits 2j..2j+1)"""
     w = words.astype(np.uint64)
@@ -361,6 +380,19 @@ def main():
                 e1.record()
                 torch.cuda.synchronize()
             extra["ascii_resident_pack_plus_count"] = {"queries": na, "queries_per_s": na / (e0.elapsed_time(e1) / 5 * 1e-3)}
+            # the host boundary itself: ASCII + offsets in host memory -> awry_count_batch -> counts in host
+            # memory; PCIe-inclusive, never the bench `value`
+            h_q = asc.cpu().numpy()
+            h_off = np.arange(na + 1, dtype=np.uint64) * np.uint64(L)
+            times = []
+            for rep in range(6):
+                tp = time.perf_counter()
+                h_counts = ix.parallel_count_csr(h_q, h_off)
+                times.append(time.perf_counter() - tp)
+            med = sorted(times[1:])[len(times[1:]) // 2]
+            assert np.array_equal(h_counts, counts[:na].cpu().numpy().view(np.uint64))
+            extra["host_boundary_end_to_end"] = {"queries": na, "queries_per_s": na / med, "ms": med * 1e3,
+                                                 "host_in_GBs": h_q.nbytes / med / 1e9, "note": "PCIe-inclusive, median of 5 after 1 warm-up"}
         result["variants"] = extra
 
         if args.cpu_seconds > 0:
@@ -371,7 +403,7 @@ def main():
             oi = oracle_ffi.OracleIndex.load(path)
             os.remove(path)
             log("oracle index via .awry round trip: %.1fs" % (time.time() - ts))
-            cores = os.cpu_count() or 1
+            cores = effective_cpus()
             sample = min(nq, 10_000_000)
             w0 = batches[W % n_batches][:sample].cpu().numpy().view(np.uint64)
             qb, qo = synth.fixed_to_csr(unpack_nt2(w0, L))
@@ -392,7 +424,8 @@ def main():
             parity = bool(np.array_equal(gcounts, ocounts))
             result["cpu_baseline"] = {"value": sample / dt, "unit": "queries/s", "cores": cores, "kind": "port",
                                       "sample": "first %d queries of timed batch 0 x %d passes (same index via .awry v1 round trip), "
-                                                "reference step schedule, %d threads, %.1f s total" % (sample, passes, cores, dt * passes),
+                                                "reference step schedule, %d threads = this job's CPU quota (%d logical CPUs on the host), "
+                                                "%.1f s total" % (sample, passes, cores, os.cpu_count() or 0, dt * passes),
                                       "steps_per_query": otally["steps"] / sample,
                                       "block_reads_per_query": otally["block_reads"] / sample,
                                       "gpu_matches_oracle_on_sample": parity}

@@ -475,3 +475,36 @@ def test_fuzz_small_indexes_against_oracle(oracle):
                     wl = oi.parallel_locate(*synth.fixed_to_csr(q2d), 2)[:3]
                     assert all(np.array_equal(x, y) for x, y in zip(got, wl)), (trial, L, verify)
                 ix.set_verify(-1)
+
+
+def test_concurrent_host_threads_share_one_index(oracle):
+    """the handle is immutable after set_devices: query entry points may be called from several host threads at once
+    (the reference's FmIndex is Send + Sync)"""
+    import threading
+    text, st, hd = synth.make_text(200000, 0, 33, 2, 0.03)
+    ix = gpu_index(text, 0, 8, 0, st, hd)
+    oi = oracle.OracleIndex.from_text(text, 0, 8, 0, st, hd)
+    jobs = []
+    for t in range(6):
+        L = (12, 20, 31, 40, 9, 33)[t]
+        q2d = np.concatenate([synth.sampled_queries(text, 3000, L, t), synth.random_queries(2000, L, 0, 50 + t)])
+        qb, qo = synth.fixed_to_csr(q2d)
+        jobs.append((qb, qo, oi.parallel_count(qb, qo, 2)[0], oi.parallel_locate(qb, qo, 2)[:3]))
+    errors = []
+
+    def work(j):
+        try:
+            qb, qo, want_c, want_l = jobs[j]
+            for _ in range(3):
+                assert np.array_equal(ix.parallel_count_csr(qb, qo), want_c)
+                got = ix.parallel_locate_csr(qb, qo)
+                assert all(np.array_equal(x, y) for x, y in zip(got, want_l))
+        except Exception as e:  # noqa: BLE001
+            errors.append((j, repr(e)))
+
+    threads = [threading.Thread(target=work, args=(j,)) for j in range(len(jobs))]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors

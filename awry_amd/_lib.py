@@ -99,6 +99,7 @@ def load_library():
     sig("awry_sequence_start", u64, vp, u64)
     sig("awry_sequence_header", cp, vp, u64)
     sig("awry_block_reference_layout", i32, vp, u64, u64p, u64)
+    sig("awry_read_query_file", i32, cp, C.POINTER(u8p), C.POINTER(u64p), u64p)
     sig("awry_host_suffix_array", i32, vp, u64, u64p)
     sig("awry_symbol_index", u8, i32, u8)
     sig("awry_dev_pack_nt2", i32, vp, i32, vp, u64, i32, vp, vp, vp)

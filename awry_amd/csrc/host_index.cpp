@@ -41,43 +41,63 @@ static std::string first_token(const char* p, size_t n) {
   return std::string(p, k);
 }
 
-// Text model of src/fm_index.rs:148-153,182,220-223: records joined by one delimiter byte ('N' / 'X'),
-// one trailing '$'.  The reader itself (libsufr::util::read_sequence_file) is not in the reference tree;
-// letters are upper-cased (ignore_softmask: true, src/fm_index.rs:161) and the header is the first
-// whitespace-delimited token.  Parity is pinned only for upper-case canonical letters (SURVEY.md 8c).
-SequenceFile read_sequence_file(const std::string& path, int alphabet) {
+// FASTA (multi-line records) or FASTQ (4-line records) -> fn(header token, sequence bytes as written)
+template <class F>
+static void for_each_record(const std::string& path, F&& fn) {
   std::ifstream in(path, std::ios::binary);
   if (!in) throw std::runtime_error("cannot open sequence file: " + path);
-  SequenceFile sf;
-  const uint8_t delim = alphabet == NUCLEOTIDE ? 'N' : 'X';
-  std::string line;
-  bool first = true, fastq = false;
+  std::string line, header, seq;
+  bool first = true, fastq = false, open_rec = false;
   int state = 0;  // fastq: 0 header, 1 sequence, 2 '+', 3 quality
+  auto flush = [&] { if (open_rec) fn(header, seq); open_rec = false; seq.clear(); };
   while (std::getline(in, line)) {
     while (!line.empty() && (line.back() == '\r' || line.back() == '\n')) line.pop_back();
     if (first && !line.empty()) { fastq = line[0] == '@'; first = false; }
     bool is_header = fastq ? state == 0 : (!line.empty() && line[0] == '>');
     if (is_header) {
       if (line.empty()) continue;
-      if (!sf.starts.empty()) sf.text.push_back(delim);
-      sf.starts.push_back(sf.text.size());
-      sf.headers.push_back(first_token(line.data() + 1, line.size() - 1));
+      flush();
+      header = first_token(line.data() + 1, line.size() - 1);
+      open_rec = true;
       if (fastq) state = 1;
       continue;
     }
     if (fastq && state == 2) { state = 3; continue; }
     if (fastq && state == 3) { state = 0; continue; }
-    if (sf.starts.empty() && !line.empty()) {  // sequence data before any header
-      sf.starts.push_back(0);
-      sf.headers.emplace_back("");
-    }
+    if (!open_rec && !line.empty()) { header.clear(); open_rec = true; }  // sequence data before any header
     for (char c : line)
-      if (!isspace((unsigned char)c)) sf.text.push_back((uint8_t)toupper((unsigned char)c));
+      if (!isspace((unsigned char)c)) seq.push_back(c);
     if (fastq) state = 2;
   }
+  flush();
+}
+
+// Text model of src/fm_index.rs:148-153,182,220-223: records joined by one delimiter byte ('N' / 'X'),
+// one trailing '$'.  The reader itself (libsufr::util::read_sequence_file) is not in the reference tree;
+// letters are upper-cased (ignore_softmask: true, src/fm_index.rs:161) and the header is the first
+// whitespace-delimited token.  Parity is pinned only for upper-case canonical letters (SURVEY.md 8c).
+SequenceFile read_sequence_file(const std::string& path, int alphabet) {
+  SequenceFile sf;
+  const uint8_t delim = alphabet == NUCLEOTIDE ? 'N' : 'X';
+  for_each_record(path, [&](const std::string& header, const std::string& seq) {
+    if (!sf.starts.empty()) sf.text.push_back(delim);
+    sf.starts.push_back(sf.text.size());
+    sf.headers.push_back(header);
+    for (char c : seq) sf.text.push_back((uint8_t)toupper((unsigned char)c));
+  });
   if (sf.starts.empty()) throw std::runtime_error("no sequence records in " + path);
   sf.text.push_back('$');
   return sf;
+}
+
+// query ingestion: every record of a FASTA/FASTQ file becomes one query of a CSR batch
+void read_query_file(const std::string& path, std::vector<uint8_t>& bytes, std::vector<uint64_t>& offsets) {
+  bytes.clear();
+  offsets.assign(1, 0);
+  for_each_record(path, [&](const std::string&, const std::string& seq) {
+    bytes.insert(bytes.end(), seq.begin(), seq.end());
+    offsets.push_back(bytes.size());
+  });
 }
 
 // ------------------------------------------------------------------ packing

@@ -91,6 +91,19 @@ def pack_queries(queries: Iterable):
 _u64p = C.POINTER(C.c_uint64)
 
 
+def read_query_file(path):
+    """FASTA / FASTQ file -> (uint8 bytes, uint64 offsets[n+1]): one query per record (query ingestion)"""
+    L = _lib.load_library()
+    b, o, n = C.POINTER(C.c_uint8)(), _u64p(), C.c_uint64()
+    _check(L.awry_read_query_file(os.fsencode(path), C.byref(b), C.byref(o), C.byref(n)))
+    off = np.ctypeslib.as_array(o, shape=(int(n.value) + 1,)).copy()
+    tot = int(off[-1])
+    qb = np.ctypeslib.as_array(b, shape=(tot,)).copy() if tot else np.zeros(0, np.uint8)
+    L.awry_free_buffer(b)
+    L.awry_free_buffer(o)
+    return qb, off
+
+
 class FmIndex:
     def __init__(self, handle):
         self._L = _lib.load_library()

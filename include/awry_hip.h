@@ -137,6 +137,9 @@ int awry_block_reference_layout(const awry_index_t *idx, uint64_t block, uint64_
 const char *awry_last_error(void); /* thread-local message of the last non-zero status */
 
 /* ---- host utilities ----------------------------------------------------------------------------------- */
+/* query ingestion: every record of a FASTA / FASTQ file becomes one query; library-allocated CSR arrays
+ * (awry_free_buffer) ready for awry_count_batch / awry_locate_batch */
+int awry_read_query_file(const char *path, uint8_t **qbytes_out, uint64_t **qoff_out, uint64_t *n_out);
 /* suffix array of a byte text ending in '$' (host SA-IS; stands in for libsufr, src/fm_index.rs:156-181) */
 int awry_host_suffix_array(const uint8_t *text, uint64_t n, uint64_t *sa_out);
 uint8_t awry_symbol_index(int alphabet, uint8_t ascii); /* Symbol::new_ascii(..).index(), src/alphabet.rs:109,152 */

@@ -145,3 +145,19 @@ def test_argument_errors():
     assert e.value.code in (ERR_IO, ERR_ARG)
     with pytest.raises(AwryError):
         FmIndex.from_text(b"ACGT$", 2)
+
+
+def test_query_file_ingestion(tmp_path):
+    """FASTA (wrapped lines) and FASTQ records become CSR query batches, bytes as written"""
+    from awry_amd.fm_index import read_query_file
+    fa = tmp_path / "q.fa"
+    fa.write_bytes(b">a desc\nACGT\nacgtN\n>b\n\nGG\n>c\nT\n")
+    qb, qo = read_query_file(str(fa))
+    assert qo.tolist() == [0, 9, 11, 12] and bytes(qb) == b"ACGTacgtNGGT"
+    fq = tmp_path / "q.fq"
+    fq.write_bytes(b"@r1\nACGTT\n+\nIIIII\n@r2 x\nGATTACA\n+r2\n@@@@@@@\n")
+    qb, qo = read_query_file(str(fq))
+    assert qo.tolist() == [0, 5, 12] and bytes(qb) == b"ACGTTGATTACA"
+    with pytest.raises(AwryError) as e:
+        read_query_file(str(tmp_path / "missing.fq"))
+    assert e.value.code == ERR_IO

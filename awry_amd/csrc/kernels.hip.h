@@ -13,6 +13,17 @@
 //     independent queries, one per QUAD of lanes; a quad fetches a 128-B block as 2 x
 //     global_load_dwordx4 per lane (4 lanes x 16 B = one 64-B half line per instruction), ranks its
 //     64-symbol slice with __popcll and sums partials with two quad_perm DPP adds -- no LDS round trip.
+//
+// Kernel map (default in CAPS; the others are kept as measured alternatives):
+//   count, any query      count_scalar_kernel<A>         ASCII + offsets, one query per lane, seed probe when possible
+//   count, packed k-mers  COUNT_NT2_QUAD4_KERNEL         groups of four queries per quad, grouped seed probes
+//                         count_nt2_quad_kernel          one strided query per quad
+//                         count_nt2_chunk_kernel         queries/results staged through LDS per wave
+//   count, packed reads   COUNT_NT2_READS_KERNEL         any length, multi-word; optional seed-and-verify
+//   locate                LOCATE_TILE_KERNEL<A>          tiles of hits, per-lane walk state machines, dense SA
+//                         locate_scalar_kernel<A>        one hit per lane (round-1 baseline)
+//   accelerators          seed_level1/extend/finalize, densify_sa_kernel, text4_scatter_kernel
+//   glue                  pack_nt2_kernel, scan_*_kernel, ref_kmer_table_kernel, scalar_ops_kernel
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -646,7 +657,6 @@ __global__ __launch_bounds__(256) void count_nt2_chunk_kernel(DevIndex ix, const
     if (c >= nchunks) break;
     const uint64_t base = c * NT2_CHUNK;
     const int cn = (int)(n - base < (uint64_t)NT2_CHUNK ? n - base : (uint64_t)NT2_CHUNK);
-#pragma unroll
     for (int j = 0; j < NT2_CHUNK / 64; j++) {
       const int s = j * 64 + lane;
       lds[s] = s < cn ? queries[base + s] : 0ull;
@@ -701,7 +711,6 @@ __global__ __launch_bounds__(256) void count_nt2_chunk_kernel(DevIndex ix, const
         }
       }
     }
-#pragma unroll
     for (int j = 0; j < NT2_CHUNK / 64; j++) {
       const int s = j * 64 + lane;
       if (s < cn) counts[base + s] = lds[s];

@@ -9,6 +9,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <memory>
 #include <mutex>
 #include <new>
@@ -89,6 +90,10 @@ struct Replica {
   DevBuf<uint32_t> dense_sa;                  // SA[j * dense_ratio] as u32 (device-only accelerator for locate)
   uint32_t dense_ratio = 0;                   // 0 = use the file's bit-packed samples
   std::atomic<unsigned> launch_seq{0};
+  // survivor lists of the two-phase count schedule, one per stream (launches on one stream are ordered, so reuse is safe)
+  struct SurvScratch { DevBuf<uint64_t> w, range; DevBuf<uint32_t> q, count; uint64_t cap = 0; };
+  std::mutex scratch_mu;
+  std::map<hipStream_t, std::unique_ptr<SurvScratch>> scratch;
   int seed_k = 0;
   int num_cus = 256;
   DevIndex dev{};
@@ -141,6 +146,7 @@ int count_kernel_mode() {
   if (e && !strcmp(e, "strided")) return 0;
   if (e && !strcmp(e, "chunk")) return 1;
   if (e && !strcmp(e, "quad4")) return 2;
+  if (e && !strcmp(e, "twophase")) return 3;
   // measured on MI355X, GRCh38-scale, 10 M random 31-mers per launch (tools/ab_count.py):
   //   seed k=16: strided 17.9, quad4 19.4, chunk 13.8 G queries/s;  k=14: 10.1 / 10.1 / 9.9
   return 2;
@@ -388,7 +394,37 @@ void launch_count_nt2(Replica& r, const uint64_t* d_words, uint64_t n, int L, ui
     HIP_CHECK(hipGetLastError());
     return;
   }
-  if (kmode == 2) {  // groups of 4 consecutive queries per quad: whole-sector result writes
+  if (kmode == 3 && seeded && !(r.dev.text4 != nullptr && r.dev.dense_ratio == 1) && n < (1ull << 32)) {
+    // two-phase: per-lane seed probes decide most queries, the quad machinery resumes the survivors
+    Replica::SurvScratch* sc;
+    {
+      std::lock_guard<std::mutex> lock(r.scratch_mu);
+      auto& slot = r.scratch[s];
+      if (!slot) slot = std::make_unique<Replica::SurvScratch>();
+      sc = slot.get();
+    }
+    const unsigned nblk = (unsigned)r.num_cus * 8;                       // both phases use this grid
+    const uint64_t per_block = ((n + (uint64_t)nblk * 256 - 1) / ((uint64_t)nblk * 256)) * 256;  // queries a block sees
+    const uint64_t total = per_block * nblk;
+    if (sc->cap < total) {
+      HIP_CHECK(hipStreamSynchronize(s));
+      sc->w.alloc(total); sc->range.alloc(total); sc->q.alloc(total);
+      if (!sc->count.p) sc->count.alloc(nblk);
+      sc->cap = total;
+    }
+    const Nt2Survivors sv{sc->w.p, sc->range.p, sc->q.p, sc->count.p, per_block};
+    const dim3 gp(nblk);
+    if (d_tally) {
+      hipLaunchKernelGGL(count_nt2_probe_kernel<true>, gp, b, 0, s, r.dev, d_words, n, L, d_counts, sv, d_tally);
+      hipLaunchKernelGGL(count_nt2_resume_kernel<true>, gp, b, 0, s, r.dev, sv, L, d_counts, d_tally);
+    } else {
+      hipLaunchKernelGGL(count_nt2_probe_kernel<false>, gp, b, 0, s, r.dev, d_words, n, L, d_counts, sv, d_tally);
+      hipLaunchKernelGGL(count_nt2_resume_kernel<false>, gp, b, 0, s, r.dev, sv, L, d_counts, d_tally);
+    }
+    HIP_CHECK(hipGetLastError());
+    return;
+  }
+  if (kmode == 2 || kmode == 3) {  // groups of 4 consecutive queries per quad: whole-sector result writes
     const dim3 g4(grid_for(r, n, 256));
     const bool verify = r.dev.text4 != nullptr && r.dev.dense_ratio == 1;
 #define AWRY_LAUNCH_QUAD4(S, T, V) hipLaunchKernelGGL((count_nt2_quad4_kernel<S, T, V>), g4, b, 0, s, r.dev, d_words, n, L, d_counts, d_tally)
@@ -796,8 +832,19 @@ int awry_set_devices(awry_index_t* idx, const int* device_ids, int n_devices) {
   return guarded([&] {
     require(idx != nullptr, "null index");
     if (n_devices <= 0 || !device_ids) throw NoDeviceError("awry_set_devices needs at least one GPU: there is no CPU search path");
-    std::vector<std::unique_ptr<Replica>> reps;
-    for (int i = 0; i < n_devices; i++) reps.push_back(make_replica(idx, device_ids[i]));
+    std::vector<std::unique_ptr<Replica>> reps(n_devices);
+    if (n_devices == 1) {
+      reps[0] = make_replica(idx, device_ids[0]);
+    } else {  // one host thread per GPU: upload + seed-table build run concurrently on all of them
+      std::vector<std::exception_ptr> errs(n_devices);
+      std::vector<std::thread> pool;
+      for (int i = 0; i < n_devices; i++)
+        pool.emplace_back([&, i] {
+          try { reps[i] = make_replica(idx, device_ids[i]); } catch (...) { errs[i] = std::current_exception(); }
+        });
+      for (auto& t : pool) t.join();
+      for (auto& e : errs) if (e) std::rethrow_exception(e);
+    }
     idx->reps = std::move(reps);
   });
 }

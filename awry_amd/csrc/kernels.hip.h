@@ -627,6 +627,136 @@ __global__ __launch_bounds__(256) void count_nt2_quad4_kernel(DevIndex ix, const
   }
 }
 
+// Two-phase schedule for seeded k-mer batches.  With 4^k ~ bwt_len three quarters of all random queries are decided
+// by their seed entry alone (absent k-mer, or a singleton whose BWT symbol is not the next letter), so
+//   phase 1 (this kernel): one query per LANE, fully coalesced query reads and count writes, 64 independent seed
+//     probes per wave instruction and two queries in flight per lane -- no dependent chain beyond query -> entry;
+//     queries that need LF steps are appended (wave ballot + one atomic per wave) to a compact survivor list;
+//   phase 2 (count_nt2_resume_kernel): the quad machinery on the survivors only, resuming from the probed range.
+struct Nt2Survivors {
+  uint64_t* w;                 // query words
+  uint64_t* range;             // sp | cnt << 32 as probed (cnt == SEED_CNT_SAT: restart without the table)
+  uint32_t* q;                 // original query index
+  uint32_t* count;             // survivors per phase-1 block (block b owns slots [b * cap, (b + 1) * cap))
+  uint64_t cap;                // slots per block
+};
+
+template <bool TALLY>
+__global__ __launch_bounds__(256) void count_nt2_probe_kernel(DevIndex ix, const uint64_t* __restrict__ queries, uint64_t n, int L,
+                                                              uint64_t* __restrict__ counts, Nt2Survivors sv,
+                                                              unsigned long long* __restrict__ tally) {
+  __shared__ unsigned int s_count;  // a single device-wide list head would serialise ~150 k wave-level atomics (1.8 ms)
+  if (threadIdx.x == 0) s_count = 0;
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const SeedEntry* __restrict__ seed = ix.seed;
+  const int k = ix.seed_k, i0 = L - k, kshift = 2 * (L - k);
+  const uint64_t kmask = (1ull << (2 * k)) - 1;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  const uint64_t lane_lt = (1ull << lane) - 1;
+  const uint64_t region = (uint64_t)blockIdx.x * sv.cap;
+  // the trip count is wave-uniform (ballots and the wave-level atomic below need every lane of the wave)
+  for (uint64_t wbase = (uint64_t)blockIdx.x * blockDim.x + (threadIdx.x & ~63u); wbase < n; wbase += 2 * stride) {
+    const uint64_t qa = wbase + lane, qb = qa + stride;
+    const bool va = qa < n, vb = qb < n;
+    const uint64_t wa = va ? queries[qa] : 0, wb = vb ? queries[qb] : 0;
+    SeedEntry ea{1u, 0u}, eb{1u, 0u};
+    if (va) ea = seed[(uint32_t)((wa >> kshift) & kmask)];  // both probes are issued before either is used
+    if (vb) eb = seed[(uint32_t)((wb >> kshift) & kmask)];
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      const bool valid = h ? vb : va;
+      const uint64_t q = h ? qb : qa, w = h ? wb : wa;
+      const SeedEntry e = h ? eb : ea;
+      const uint32_t cnt = seed_cnt(e);
+      bool survivor = false;
+      uint64_t value = 0;
+      if (valid) {
+        if (cnt == SEED_CNT_SAT) survivor = true;
+        else if (cnt == 0u) value = 0;
+        else if (i0 == 0) value = cnt;
+        else if (cnt == 1u) {
+          const uint32_t nc = (uint32_t)(w >> (2 * (i0 - 1))) & 3u;
+          survivor = seed_sym(e) == (int)(nc == 3u ? 5u : nc + 1u);  // else BWT[sp] is not the next letter: absent
+        } else survivor = true;
+        counts[q] = value;  // coalesced; survivors are overwritten by phase 2
+      }
+      const uint64_t sm = __ballot(survivor);
+      if (sm) {
+        unsigned int slot0 = 0;
+        if (lane == 0) slot0 = atomicAdd(&s_count, (unsigned int)__popcll(sm));
+        slot0 = __shfl(slot0, 0, 64);
+        if (survivor) {
+          const uint64_t s = region + slot0 + (uint64_t)__popcll(sm & lane_lt);
+          sv.w[s] = w;
+          sv.range[s] = (uint64_t)e.sp | ((uint64_t)cnt << 32);
+          sv.q[s] = (uint32_t)q;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) sv.count[blockIdx.x] = s_count;
+  if (TALLY && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&tally[0], (unsigned long long)n);
+}
+
+// same grid as phase 1: block b resumes the survivors block b recorded
+template <bool TALLY>
+__global__ __launch_bounds__(256) void count_nt2_resume_kernel(DevIndex ix, Nt2Survivors sv, int L, uint64_t* __restrict__ counts,
+                                                               unsigned long long* __restrict__ tally) {
+  const int l = threadIdx.x & 3;
+  const uint64_t ns = sv.count[blockIdx.x];
+  const uint64_t region = (uint64_t)blockIdx.x * sv.cap;
+  uint64_t r = threadIdx.x >> 2;  // 64 quads per block walk the block's list
+  const uint64_t* __restrict__ blocks = ix.blocks;
+  const int k = ix.seed_k;
+  const uint32_t cA = (uint32_t)ix.prefix_sums[1], cC = (uint32_t)ix.prefix_sums[2], cG = (uint32_t)ix.prefix_sums[3],
+                 cN = (uint32_t)ix.prefix_sums[4], cT = (uint32_t)ix.prefix_sums[5], cEnd = (uint32_t)ix.prefix_sums[6];
+  bool have = r < ns, fresh = true;
+  uint64_t w = 0;
+  uint32_t sp = 1, ep = 0, qidx = 0;
+  int i = 0;
+  uint32_t t_step = 0, t_blk = 0;
+  while (__any(have)) {
+    if (have) {
+      if (fresh) {  // the record replaces the seed probe; the first step follows in the same iteration
+        w = sv.w[region + r];
+        const uint64_t rg = sv.range[region + r];
+        qidx = sv.q[region + r];
+        const uint32_t cnt = (uint32_t)(rg >> 32);
+        if (cnt == SEED_CNT_SAT) {
+          const uint32_t c = (uint32_t)(w >> (2 * (L - 1))) & 3u;
+          sp = c == 0 ? cA : (c == 1 ? cC : (c == 2 ? cG : cT));
+          ep = (c == 0 ? cC : (c == 1 ? cG : (c == 2 ? cN : cEnd))) - 1;
+          i = L - 1;
+        } else {
+          sp = (uint32_t)rg;
+          ep = sp + cnt - 1u;
+          i = L - k;
+        }
+        fresh = false;
+      }
+      if (i > 0 && sp <= ep) {
+        i--;
+        const uint32_t c = (uint32_t)(w >> (2 * i)) & 3u;
+        const uint32_t cl = c == 0 ? cA : (c == 1 ? cC : (c == 2 ? cG : cT));
+        if (TALLY) { t_step++; t_blk += ((sp - 1) >> 8) == (ep >> 8) ? 1u : 2u; }
+        quad_step(blocks, cl, sp, ep, c, l);
+      }
+      if (sp > ep || i == 0) {
+        if (l == 0) counts[qidx] = sp > ep ? 0ull : (uint64_t)(ep - sp) + 1ull;
+        r += 64;
+        have = r < ns;
+        fresh = true;
+      }
+    }
+  }
+  if (TALLY && l == 0) {
+    atomicAdd(&tally[1], (unsigned long long)t_step);
+    atomicAdd(&tally[2], (unsigned long long)t_blk);
+  }
+}
+
 // v2 of the hot kernel: the query and result streams are staged through LDS in wave-private chunks so that
 // both move as whole 128-B lines (v1 fetched one line per 8-B query word and wrote one partial line per
 // 8-B result: 2 of its ~4 line requests per query).  A wave grabs a chunk of CHUNK consecutive queries with

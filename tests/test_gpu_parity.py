@@ -508,3 +508,25 @@ def test_concurrent_host_threads_share_one_index(oracle):
     for th in threads:
         th.join()
     assert not errors, errors
+
+
+def test_all_count_kernel_schedules_agree(oracle):
+    """the four schedules of the packed k-mer kernel (strided quads, LDS chunks, groups of four, two-phase
+    probe + resume) are interchangeable: identical counts = the oracle's, including ragged tails and tiny batches"""
+    from awry_amd import _lib
+    L_ = _lib.load_library()
+    text, st, hd = synth.make_text(500000, 0, 71, 2, 0.04)
+    ix = gpu_index(text, 0, 8, 0, st, hd)
+    oi = oracle.OracleIndex.from_text(text, 0, 8, 0, st, hd)
+    try:
+        for L, nq in ((31, 40003), (17, 1), (9, 2), (32, 257), (12, 1023)):
+            q2d = np.concatenate([synth.sampled_queries(text, nq // 2 + 1, L, L), synth.random_queries(nq // 2, L, 0, L + 1)])[:nq]
+            want, _ = oi.parallel_count(*synth.fixed_to_csr(q2d), 4)
+            for k in (-1, 5):
+                ix.set_seed_kmer_len(k)
+                for mode in (0, 1, 2, 3):
+                    L_.awry_debug_set_count_kernel(mode)
+                    assert np.array_equal(ix.count_kmers_nt2(q2d, True), want), (L, nq, k, mode)
+                    assert np.array_equal(ix.count_kmers_nt2(q2d, False), want), (L, nq, k, mode)
+    finally:
+        L_.awry_debug_set_count_kernel(-1)

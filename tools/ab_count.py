@@ -14,13 +14,13 @@ L, nq = 31, 10_000_000
 dev = torch.device("cuda", 0)
 gen = torch.Generator(device=dev); gen.manual_seed(7)
 batches = [torch.randint(0, 1 << 62, (nq,), dtype=torch.int64, device=dev, generator=gen) for _ in range(4)]
-counts = [torch.zeros(nq, dtype=torch.int64, device=dev) for _ in range(3)]
+counts = [torch.zeros(nq, dtype=torch.int64, device=dev) for _ in range(4)]
 stream = torch.cuda.current_stream().cuda_stream
 lib = _lib.load_library()
 for k in ks:
     ix.set_seed_kmer_len(k)
     res = {}
-    for mode, name in ((0, "strided"), (2, "quad4"), (1, "chunk")):
+    for mode, name in ((0, "strided"), (2, "quad4"), (3, "twophase")):
         lib.awry_debug_set_count_kernel(mode)
         for i in range(2): ix.dev_count_nt2(batches[i].data_ptr(), nq, L, counts[mode].data_ptr(), True, stream, 0)
         torch.cuda.synchronize()
@@ -32,5 +32,5 @@ for k in ks:
             b.record(); torch.cuda.synchronize()
             best = min(best, a.elapsed_time(b) / 8)
         res[name] = best
-    same = bool(torch.equal(counts[0], counts[2]) and torch.equal(counts[0], counts[1]))
+    same = bool(torch.equal(counts[0], counts[2]) and torch.equal(counts[0], counts[3]))
     print("k=%d  " % k + "  ".join("%s %.3f ms (%.2f Gq/s)" % (nm, ms, nq / ms / 1e6) for nm, ms in res.items()) + "  identical=%s" % same, flush=True)

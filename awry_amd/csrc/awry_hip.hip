@@ -139,7 +139,8 @@ int grid_for(const Replica& r, uint64_t work_items, int per_block, int blocks_pe
 
 // which instantiation serves awry_dev_count_nt2: 0 strided quads, 1 LDS-staged chunks, 2 groups of four
 std::atomic<int> g_count_kernel{-1};
-int count_kernel_mode() {
+// -1: no explicit choice (env / policy)
+int count_kernel_override() {
   int m = g_count_kernel.load();
   if (m >= 0) return m;
   const char* e = getenv("AWRY_COUNT_KERNEL");
@@ -147,8 +148,19 @@ int count_kernel_mode() {
   if (e && !strcmp(e, "chunk")) return 1;
   if (e && !strcmp(e, "quad4")) return 2;
   if (e && !strcmp(e, "twophase")) return 3;
-  // measured on MI355X, GRCh38-scale, 10 M random 31-mers per launch (tools/ab_count.py):
-  //   seed k=16: strided 17.9, quad4 19.4, chunk 13.8 G queries/s;  k=14: 10.1 / 10.1 / 9.9
+  return -1;
+}
+// Policy, from measurements on MI355X, GRCh38-scale, 10 M random 31-mers per launch (tools/ab_count.py, G queries/s):
+//   seed k   strided  quad4  chunk  twophase
+//     14      10.1    10.3    9.9     8.2
+//     16      19.4    21.8   14.4    21.3
+//     17      25.3    28.1     -     29.9
+// quad4 is the general default; once the table is so sparse that most queries are decided by their entry alone
+// (4^k >= 3 bwt_len) the per-lane probe pass of the two-phase schedule wins.
+int count_kernel_mode(uint64_t bwt_len, int seed_k, bool seeded) {
+  const int m = count_kernel_override();
+  if (m >= 0) return m;
+  if (seeded && seed_k >= 1 && seed_k <= 31 && (1ull << (2 * seed_k)) / 3 >= bwt_len) return 3;
   return 2;
 }
 
@@ -156,14 +168,16 @@ bool narrow(const HostIndex& h) { return h.bwt_len < (1ull << 32) - 512; }
 
 int default_seed_k(const HostIndex& h) {
   if (h.alphabet != NUCLEOTIDE || !narrow(h)) return 0;
-  if (const char* e = getenv("AWRY_SEED_K")) return std::max(0, std::min(16, atoi(e)));
-  // about one table entry per suffix: 4^k ~ bwt_len (GRCh38: k = 16, 34 GB of the 288 GB HBM; chr1: 14; E. coli: 11).
-  // A random k-mer's range is then ~1 row, so a query costs one probe plus ~1 step instead of ~16 steps.
-  int k = (int)std::lround(std::log((double)h.bwt_len) / std::log(4.0));
-  k = std::max(1, std::min(k, 16));
+  if (const char* e = getenv("AWRY_SEED_K")) return std::max(0, std::min(17, atoi(e)));
+  // Several table entries per suffix: k = floor(log4 bwt_len) + 2, i.e. 4^k = 4..16 x bwt_len (GRCh38: k = 17, 137 GB of
+  // the 288 GB HBM; chr1: 15, 8.6 GB; E. coli: 13).  A random k-mer's entry is then empty or a singleton whose BWT
+  // symbol rarely matches, so a query costs one probe plus ~0.1 steps instead of ~16 steps (27 block reads).  The
+  // table and its build scratch (1/4 of it) must fit in 70 % of the free HBM, else k drops.
+  int k = (int)std::floor(std::log((double)h.bwt_len) / std::log(4.0)) + 2;
+  k = std::max(1, std::min(k, 17));
   size_t free_b = 0, total_b = 0;
   if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
-    while (k > 1 && (5ull << (2 * k)) * 2 > free_b / 2) k--;  // table + its build scratch within half of the free HBM
+    while (k > 1 && (double)(10ull << (2 * k)) > 0.7 * (double)free_b) k--;  // 8 B + 2 B scratch per entry
   return k;
 }
 
@@ -175,7 +189,7 @@ void build_seed(awry_index* ix, Replica& r, int k) {
   r.dev.seed_k = 0;
   if (k <= 0) return;
   require(ix->host.alphabet == NUCLEOTIDE && narrow(ix->host), "seed table needs a nucleotide index with bwt_len < 2^32");
-  require(k <= 16, "seed k-mer length must be <= 16");
+  require(k <= 17, "seed k-mer length must be <= 17");
   const uint64_t nfinal = 1ull << (2 * k);
   DevBuf<SeedEntry> a(nfinal), b(std::max<uint64_t>(4, nfinal >> 2));
   // level j lands in `a` when (k - j) is even, so the last level is in `a`
@@ -380,7 +394,7 @@ void launch_count_nt2(Replica& r, const uint64_t* d_words, uint64_t n, int L, ui
   // AWRY_COUNT_KERNEL=chunk selects the LDS-staged variant (count_nt2_chunk_kernel).  Measured on MI355X it is
   // equal at seed k=14 and 23% slower at k=16 (GRCh38-scale): the strided kernel's query words already arrive
   // as L2 hits, so staging only removes the partial-line result writes and pays chunk drain + refill for it.
-  const int kmode = count_kernel_mode();
+  const int kmode = count_kernel_mode(r.dev.bwt_len, r.seed_k, seeded);
   const bool use_chunk = kmode == 1;
   if (use_chunk) {
     unsigned long long* ctr = next_counter(r, s);
@@ -852,7 +866,7 @@ int awry_set_devices(awry_index_t* idx, const int* device_ids, int n_devices) {
 int awry_set_seed_kmer_len(awry_index_t* idx, int k) {
   return guarded([&] {
     require(idx != nullptr, "null index");
-    require(k >= -1 && k <= 16, "seed k-mer length must be in -1..16");
+    require(k >= -1 && k <= 17, "seed k-mer length must be in -1..17");
     idx->seed_k_request = k;
     for (size_t s = 0; s < idx->reps.size(); s++) {
       Replica& r = replica(idx, (int)s);
@@ -862,6 +876,17 @@ int awry_set_seed_kmer_len(awry_index_t* idx, int k) {
 }
 
 int awry_debug_set_count_kernel(int mode) { g_count_kernel.store(mode); return AWRY_OK; }
+
+const char* awry_count_schedule(const awry_index_t* idx, int L) {
+  static const char* names[] = {"count_nt2_quad_kernel", "count_nt2_chunk_kernel", "count_nt2_quad4_kernel",
+                                "count_nt2_probe_kernel+count_nt2_resume_kernel"};
+  if (!idx || idx->reps.empty()) return "";
+  const Replica& r = *idx->reps[0];
+  const bool seeded = r.seed_k > 0 && r.seed_k <= L;
+  int m = count_kernel_mode(r.dev.bwt_len, r.seed_k, seeded);
+  if (m == 3 && (!seeded || (r.dev.text4 != nullptr && r.dev.dense_ratio == 1))) m = 2;
+  return names[m & 3];
+}
 
 int awry_seed_kmer_len(const awry_index_t* idx) { return idx && !idx->reps.empty() ? idx->reps[0]->seed_k : 0; }
 int awry_num_devices(const awry_index_t* idx) { return idx ? (int)idx->reps.size() : 0; }

@@ -149,12 +149,12 @@ __global__ __launch_bounds__(256) void count_scalar_kernel(DevIndex ix, const ui
       bool seeded = false;
       if (A == NUCLEOTIDE && ix.seed && e - b >= (uint64_t)ix.seed_k) {  // last k symbols all in ACGT -> one table probe
         const int k = ix.seed_k;
-        uint32_t sidx = 0;
+        uint64_t sidx = 0;
         bool acgt = true;
         for (int j = 0; j < k; j++) {
           const int letter = nt_letter_of_index(lut[ascii[e - k + j]]);
           acgt = acgt && letter >= 0;
-          sidx |= (uint32_t)(letter & 3) << (2 * j);  // leftmost letter of the window least significant
+          sidx |= (uint64_t)(letter & 3) << (2 * j);  // leftmost letter of the window least significant
         }
         if (acgt) {
           const SeedEntry se = ix.seed[sidx];
@@ -430,7 +430,7 @@ __global__ __launch_bounds__(256) void count_nt2_quad_kernel(DevIndex ix, const 
     if (have) {
       if (fresh) {
         if (USE_SEED) {
-          const uint32_t sidx = (uint32_t)((w >> (2 * (L - k))) & ((1ull << (2 * k)) - 1));
+          const uint64_t sidx = ((w >> (2 * (L - k))) & ((1ull << (2 * k)) - 1));
           const SeedEntry e = seed[sidx];
           const uint32_t scnt = seed_cnt(e);
           sp = scnt ? e.sp : 1u;
@@ -529,7 +529,7 @@ __global__ __launch_bounds__(256) void count_nt2_quad4_kernel(DevIndex ix, const
   // the four seed probes of a group are issued together, one per lane, as soon as the group's words are there;
   // the next group's words are fetched one group ahead.  A query that the entry alone decides costs no wait.
   uint64_t eq = 0;        // this lane's seed entry (sp | cnt << 32)
-  if (USE_SEED && have) { const SeedEntry e0 = seed[(uint32_t)((wq >> kshift) & kmask)]; eq = (uint64_t)e0.sp | ((uint64_t)e0.cnt << 32); }
+  if (USE_SEED && have) { const SeedEntry e0 = seed[((wq >> kshift) & kmask)]; eq = (uint64_t)e0.sp | ((uint64_t)e0.cnt << 32); }
   uint64_t wq_next = (m + nquads < ngroups && 4 * (m + nquads) + l < n) ? queries[4 * (m + nquads) + l] : 0;
   int nvalid = have ? (int)(n - 4 * m < 4 ? n - 4 * m : 4) : 0;
   int t = 0;              // query of the group being searched
@@ -610,7 +610,7 @@ __global__ __launch_bounds__(256) void count_nt2_quad4_kernel(DevIndex ix, const
           t = 0;
           nvalid = have ? (int)(n - 4 * m < 4 ? n - 4 * m : 4) : 0;
           wq = wq_next;
-          if (USE_SEED && have) { const SeedEntry e0 = seed[(uint32_t)((wq >> kshift) & kmask)]; eq = (uint64_t)e0.sp | ((uint64_t)e0.cnt << 32); }
+          if (USE_SEED && have) { const SeedEntry e0 = seed[((wq >> kshift) & kmask)]; eq = (uint64_t)e0.sp | ((uint64_t)e0.cnt << 32); }
           wq_next = (m + nquads < ngroups && 4 * (m + nquads) + l < n) ? queries[4 * (m + nquads) + l] : 0;
         }
       }
@@ -661,8 +661,8 @@ __global__ __launch_bounds__(256) void count_nt2_probe_kernel(DevIndex ix, const
     const bool va = qa < n, vb = qb < n;
     const uint64_t wa = va ? queries[qa] : 0, wb = vb ? queries[qb] : 0;
     SeedEntry ea{1u, 0u}, eb{1u, 0u};
-    if (va) ea = seed[(uint32_t)((wa >> kshift) & kmask)];  // both probes are issued before either is used
-    if (vb) eb = seed[(uint32_t)((wb >> kshift) & kmask)];
+    if (va) ea = seed[((wa >> kshift) & kmask)];  // both probes are issued before either is used
+    if (vb) eb = seed[((wb >> kshift) & kmask)];
 #pragma unroll
     for (int h = 0; h < 2; h++) {
       const bool valid = h ? vb : va;
@@ -808,7 +808,7 @@ __global__ __launch_bounds__(256) void count_nt2_chunk_kernel(DevIndex ix, const
       if (have) {
         if (fresh) {
           if (USE_SEED) {
-            const uint32_t sidx = (uint32_t)((w >> (2 * (L - k))) & ((1ull << (2 * k)) - 1));
+            const uint64_t sidx = ((w >> (2 * (L - k))) & ((1ull << (2 * k)) - 1));
             const SeedEntry e = seed[sidx];
             const uint32_t scnt = seed_cnt(e);
             sp = scnt ? e.sp : 1u;
@@ -962,7 +962,7 @@ __global__ __launch_bounds__(256) void count_nt2_reads_kernel(DevIndex ix, const
           SeedEntry e{1u, 0u};
           uint32_t scnt = SEED_CNT_SAT;
           if (USE_SEED) {
-            e = seed[(uint32_t)(win & ((1ull << (2 * k)) - 1))];
+            e = seed[(win & ((1ull << (2 * k)) - 1))];
             scnt = seed_cnt(e);
             sp = scnt ? e.sp : 1u;
             ep = scnt ? e.sp + scnt - 1u : 0u;

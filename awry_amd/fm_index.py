@@ -171,6 +171,10 @@ class FmIndex:
     def seed_kmer_len(self) -> int:
         return self._L.awry_seed_kmer_len(self._h)
 
+    def count_schedule(self, L: int) -> str:
+        """kernel(s) dev_count_nt2 launches for k-mers of length L"""
+        return self._L.awry_count_schedule(self._h, L).decode()
+
     def num_devices(self) -> int:
         return self._L.awry_num_devices(self._h)
 

@@ -277,7 +277,7 @@ def main():
                                % (args.workload, n_text, n_rec, 100 * n_frac, nq, L, ix.seed_kmer_len()),
                    "text_len": n_text, "queries_per_gpu_per_step": nq, "query_len": L, "seed_k": ix.seed_kmer_len(),
                    "sharding": "index replicated per GPU, queries sharded by rank, no collective"},
-        "roofline": {"bound": "hbm", "kernel": "count_nt2_quad4_kernel<seed>", "achieved": alg_bytes / (kernel_ms * 1e-3) / 1e9,
+        "roofline": {"bound": "hbm", "kernel": ix.count_schedule(L), "achieved": alg_bytes / (kernel_ms * 1e-3) / 1e9,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg_bytes / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                      "traffic": None, "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": alg_bytes,
                      "census_per_launch": {"seed_probes": probes, "steps": steps_exec, "block_reads": blocks}},
@@ -285,7 +285,7 @@ def main():
 
     # HBM traffic per launch from the committed rocprofv3 PMC passes of this exact configuration (null otherwise)
     try:
-        tkey = "%s|nq=%d|L=%d|seed_k=%d|kernel=count_nt2_quad4_kernel" % (args.workload if not args.text_len else "custom", nq, L, ix.seed_kmer_len())
+        tkey = "%s|nq=%d|L=%d|seed_k=%d|kernel=%s" % (args.workload if not args.text_len else "custom", nq, L, ix.seed_kmer_len(), ix.count_schedule(L))
         tentry = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get(tkey)
         if tentry:
             result["roofline"]["traffic"] = tentry["traffic_bytes_per_launch"]

@@ -79,9 +79,11 @@ int awry_set_devices(awry_index_t *idx, const int *device_ids, int n_devices);
  * -1 picks the default.  Takes effect immediately on all replicas. */
 int awry_set_seed_kmer_len(awry_index_t *idx, int k);
 int awry_seed_kmer_len(const awry_index_t *idx);
-/* A/B switch for the packed-k-mer count kernel (process-wide; -1 default, 0 strided quads, 1 LDS-staged chunks,
- * 2 groups of four queries per quad).  All variants return identical counts. */
+/* A/B switch for the packed-k-mer count kernel (process-wide; -1 policy, 0 strided quads, 1 LDS-staged chunks,
+ * 2 groups of four queries per quad, 3 two-phase probe + resume).  All variants return identical counts. */
 int awry_debug_set_count_kernel(int mode);
+/* name(s) of the kernel(s) awry_dev_count_nt2 launches for k-mers of length L on replica 0 (for profiling reports) */
+const char *awry_count_schedule(const awry_index_t *idx, int L);
 /* device-side SA sampling used by locate (performance knob only; locations do not depend on it): 0 = walk to the
  * file's row samples (suffix_array_compression_ratio, default), r >= 1 = additionally keep SA[j r] as u32 in HBM
  * (r = 1: one read per hit, no LF walk; GRCh38: 12.4 GB).  Needs bwt_len < 2^32. */

@@ -656,18 +656,25 @@ __global__ __launch_bounds__(256) void count_nt2_probe_kernel(DevIndex ix, const
   const uint64_t lane_lt = (1ull << lane) - 1;
   const uint64_t region = (uint64_t)blockIdx.x * sv.cap;
   // the trip count is wave-uniform (ballots and the wave-level atomic below need every lane of the wave)
-  for (uint64_t wbase = (uint64_t)blockIdx.x * blockDim.x + (threadIdx.x & ~63u); wbase < n; wbase += 2 * stride) {
-    const uint64_t qa = wbase + lane, qb = qa + stride;
-    const bool va = qa < n, vb = qb < n;
-    const uint64_t wa = va ? queries[qa] : 0, wb = vb ? queries[qb] : 0;
-    SeedEntry ea{1u, 0u}, eb{1u, 0u};
-    if (va) ea = seed[((wa >> kshift) & kmask)];  // both probes are issued before either is used
-    if (vb) eb = seed[((wb >> kshift) & kmask)];
+  constexpr int NQ = 4;  // queries in flight per lane: all NQ words, then all NQ seed probes, are issued before any is used
+  for (uint64_t wbase = (uint64_t)blockIdx.x * blockDim.x + (threadIdx.x & ~63u); wbase < n; wbase += NQ * stride) {
+    uint64_t qv[NQ], wv[NQ];
+    SeedEntry ev[NQ];
 #pragma unroll
-    for (int h = 0; h < 2; h++) {
-      const bool valid = h ? vb : va;
-      const uint64_t q = h ? qb : qa, w = h ? wb : wa;
-      const SeedEntry e = h ? eb : ea;
+    for (int h = 0; h < NQ; h++) {
+      qv[h] = wbase + lane + (uint64_t)h * stride;
+      wv[h] = qv[h] < n ? queries[qv[h]] : 0;
+    }
+#pragma unroll
+    for (int h = 0; h < NQ; h++) {
+      ev[h] = SeedEntry{1u, 0u};
+      if (qv[h] < n) ev[h] = seed[(wv[h] >> kshift) & kmask];
+    }
+#pragma unroll
+    for (int h = 0; h < NQ; h++) {
+      const bool valid = qv[h] < n;
+      const uint64_t q = qv[h], w = wv[h];
+      const SeedEntry e = ev[h];
       const uint32_t cnt = seed_cnt(e);
       bool survivor = false;
       uint64_t value = 0;

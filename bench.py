@@ -294,9 +294,9 @@ def main():
         pass
     # the ceiling that actually binds this access pattern: random 128-B line requests (profiles/r01_gather_calibration.txt)
     lines = probes + blocks + nq * (8.0 + 8.0) / 128.0
-    result["roofline"]["random_line_rate"] = {"achieved_Glines_s": lines / (kernel_ms * 1e-3) / 1e9, "measured_ceiling_Glines_s": 53.0,
+    result["roofline"]["random_line_rate"] = {"achieved_Glines_s": lines / (kernel_ms * 1e-3) / 1e9, "measured_ceiling_Glines_s": 48.0,
                                               "note": "seed probe + ranked blocks + coalesced share of query/result words; ceiling = "
-                                                      "tools/calib_gather.hip on a 2 GiB table (45 on 16 GiB)"}
+                                                      "tools/calib_gather.hip: 8-B probes into a 34-137 GiB table (53 on 2 GiB; 44 when whole 128-B lines are consumed)"}
 
     if rank == 0 and world == 1:
         extra = {}

@@ -115,6 +115,7 @@ def load_library():
     sig("awry_locate_sa_ratio", i32, vp)
     sig("awry_set_verify", i32, vp, i32)
     sig("awry_verify_enabled", i32, vp)
+    sig("awry_set_verify_kmers", i32, vp, i32)
     sig("awry_dev_malloc", i32, vp, i32, u64, vpp)
     sig("awry_dev_free", i32, vp, i32, vp)
     sig("awry_dev_memcpy_h2d", i32, vp, i32, vp, vp, u64)

@@ -89,6 +89,7 @@ struct Replica {
   DevBuf<uint32_t> text4;                     // 4-bit text for seed-and-verify (device-only accelerator)
   DevBuf<uint32_t> dense_sa;                  // SA[j * dense_ratio] as u32 (device-only accelerator for locate)
   uint32_t dense_ratio = 0;                   // 0 = use the file's bit-packed samples
+  bool verify_kmers = false;                  // also use seed-and-verify in the k-mer (L <= 32) kernel
   std::atomic<unsigned> launch_seq{0};
   // survivor lists of the two-phase count schedule, one per stream (launches on one stream are ordered, so reuse is safe)
   struct SurvScratch { DevBuf<uint64_t> w, range; DevBuf<uint32_t> q, count; uint64_t cap = 0; };
@@ -115,7 +116,8 @@ struct awry_index {
   std::vector<std::unique_ptr<Replica>> reps;
   int seed_k_request = -1;      // -1 = default policy
   int dense_ratio_request = 0;  // 0 = locate walks to the file's SA samples
-  int verify_request = -1;      // < 0: seed-and-verify off; >= 0: LF steps before switching to text comparison
+  int verify_request = -2;      // -2: policy; -1: seed-and-verify off; >= 0: LF steps before switching to text comparison
+  bool verify_kmers_request = false;
 };
 
 namespace {
@@ -257,7 +259,17 @@ std::unique_ptr<Replica> make_replica(awry_index* ix, int device) {
   d.verify_after = 0;
   build_seed(ix, *r, ix->seed_k_request < 0 ? default_seed_k(h) : ix->seed_k_request);
   build_dense_sa(ix, *r, ix->dense_ratio_request);
-  if (ix->verify_request >= 0) build_verify(ix, *r, ix->verify_request);
+  int vreq = ix->verify_request;
+  if (vreq == -2) {  // policy: keep the accelerators (5 B per text symbol) resident when they fit comfortably
+    vreq = -1;
+    const char* e = getenv("AWRY_VERIFY");
+    size_t free_b = 0, total_b = 0;
+    if (!(e && !strcmp(e, "0")) && h.alphabet == NUCLEOTIDE && narrow(h) && hipMemGetInfo(&free_b, &total_b) == hipSuccess &&
+        (double)h.bwt_len * 6.0 < 0.5 * (double)free_b)
+      vreq = e && atoi(e) > 0 ? atoi(e) : 2;
+  }
+  if (vreq >= 0) build_verify(ix, *r, vreq);
+  r->verify_kmers = ix->verify_kmers_request;
   return r;
 }
 
@@ -408,7 +420,7 @@ void launch_count_nt2(Replica& r, const uint64_t* d_words, uint64_t n, int L, ui
     HIP_CHECK(hipGetLastError());
     return;
   }
-  if (kmode == 3 && seeded && !(r.dev.text4 != nullptr && r.dev.dense_ratio == 1) && n < (1ull << 32)) {
+  if (kmode == 3 && seeded && !(r.verify_kmers && r.dev.text4 != nullptr && r.dev.dense_ratio == 1) && n < (1ull << 32)) {
     // two-phase: per-lane seed probes decide most queries, the quad machinery resumes the survivors
     Replica::SurvScratch* sc;
     {
@@ -440,7 +452,7 @@ void launch_count_nt2(Replica& r, const uint64_t* d_words, uint64_t n, int L, ui
   }
   if (kmode == 2 || kmode == 3) {  // groups of 4 consecutive queries per quad: whole-sector result writes
     const dim3 g4(grid_for(r, n, 256));
-    const bool verify = r.dev.text4 != nullptr && r.dev.dense_ratio == 1;
+    const bool verify = r.verify_kmers && r.dev.text4 != nullptr && r.dev.dense_ratio == 1;
 #define AWRY_LAUNCH_QUAD4(S, T, V) hipLaunchKernelGGL((count_nt2_quad4_kernel<S, T, V>), g4, b, 0, s, r.dev, d_words, n, L, d_counts, d_tally)
     if (verify) {
       if (d_tally) { if (seeded) AWRY_LAUNCH_QUAD4(true, true, true); else AWRY_LAUNCH_QUAD4(false, true, true); }
@@ -884,7 +896,7 @@ const char* awry_count_schedule(const awry_index_t* idx, int L) {
   const Replica& r = *idx->reps[0];
   const bool seeded = r.seed_k > 0 && r.seed_k <= L;
   int m = count_kernel_mode(r.dev.bwt_len, r.seed_k, seeded);
-  if (m == 3 && (!seeded || (r.dev.text4 != nullptr && r.dev.dense_ratio == 1))) m = 2;
+  if (m == 3 && (!seeded || (r.verify_kmers && r.dev.text4 != nullptr && r.dev.dense_ratio == 1))) m = 2;
   return names[m & 3];
 }
 
@@ -1121,6 +1133,13 @@ int awry_set_verify(awry_index_t* idx, int after_steps) {
     idx->verify_request = after_steps;
     if (after_steps >= 0) idx->dense_ratio_request = 1;
     for (size_t s = 0; s < idx->reps.size(); s++) build_verify(idx, replica(idx, (int)s), after_steps);
+  });
+}
+int awry_set_verify_kmers(awry_index_t* idx, int on) {
+  return guarded([&] {
+    require(idx != nullptr, "null index");
+    idx->verify_kmers_request = on != 0;
+    for (auto& r : idx->reps) r->verify_kmers = on != 0;
   });
 }
 int awry_verify_enabled(const awry_index_t* idx) { return idx && !idx->reps.empty() && idx->reps[0]->dev.text4 != nullptr; }

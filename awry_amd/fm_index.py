@@ -372,6 +372,10 @@ class FmIndex:
         """seed-and-verify for packed nucleotide reads (-1 = off); results do not depend on it"""
         _check(self._L.awry_set_verify(self._h, after_steps))
 
+    def set_verify_kmers(self, on: bool):
+        """let the k-mer (L <= 32) kernel use seed-and-verify too (pays off on batches of present k-mers)"""
+        _check(self._L.awry_set_verify_kmers(self._h, 1 if on else 0))
+
     def verify_enabled(self) -> bool:
         return bool(self._L.awry_verify_enabled(self._h))
 

@@ -68,6 +68,8 @@ def locate_benchmark(ix, text, torch, dev, stream, n_reads, read_len, oi=None, c
     Pipeline on the device: packed reads -> seeded quad count (+range starts) -> scan -> tile locate.  Timed per phase
     with HIP events, for the file's row samples (ratio 8, mean ~7 LF steps per hit) and for the dense device SA."""
     from tests import synth
+    ix.set_verify(-1)  # the default policy keeps the accelerators resident; measure the plain pipelines first
+    ix.set_locate_sa_ratio(0)
     reads = synth.sampled_queries(text, n_reads, read_len, 4242)
     W = (read_len + 31) // 32
     d_ascii = torch.from_numpy(reads.reshape(-1)).to(dev)
@@ -133,8 +135,6 @@ def locate_benchmark(ix, text, torch, dev, stream, n_reads, read_len, oi=None, c
                               "locate_kernel_ms": ms_loc_v, "hits_per_s": total / (ms_loc_v * 1e-3),
                               "end_to_end_reads_per_s_device_resident": n_reads / ((ms_count_v + ms_scan_v + ms_loc_v) * 1e-3),
                               "accelerator_build_s": build_s, "identical_locations": True}
-    ix.set_verify(-1)
-    ix.set_locate_sa_ratio(0)
     if oi is not None:
         ns = min(n_reads, 200_000)
         qb, qo = synth.fixed_to_csr(reads[:ns])
@@ -349,6 +349,7 @@ def main():
             # the same present k-mers with seed-and-verify (dense SA + 4-bit text resident in HBM)
             want_present = counts[:ns].clone()
             ix.set_verify(2)
+            ix.set_verify_kmers(True)
             for _ in range(2):
                 ix.dev_count_nt2(d_words.data_ptr(), ns, L, counts.data_ptr(), True, stream, 0)
             e0.record()
@@ -366,8 +367,7 @@ def main():
             torch.cuda.synchronize()
             extra["seed_and_verify"] = {"present_queries_per_s": ns / (msv * 1e-3), "present_kernel_ms": msv,
                                         "random_queries_per_s": nq / (e0.elapsed_time(e1) / 5 * 1e-3), "identical_counts": True}
-            ix.set_verify(-1)
-            ix.set_locate_sa_ratio(0)
+            ix.set_verify_kmers(False)
             # ASCII boundary with on-device packing in the timed region (31 B/query read instead of 8 B)
             na = min(nq, 5_000_000)
             asc = torch.from_numpy(unpack_nt2(batches[0][:na].cpu().numpy().view(np.uint64), L).reshape(-1)).to(dev)

@@ -93,8 +93,12 @@ int awry_locate_sa_ratio(const awry_index_t *idx);
  * keeps the ratio-1 dense SA and the text as 4-bit codes in HBM (GRCh38: 12.4 + 1.55 GB), both recovered from the
  * index on the device.  Once a range holds <= 8 rows and `after_steps` LF steps have run, the rest of the read is
  * compared with the text in front of each candidate instead of being matched by one dependent LF step per symbol.
- * after_steps = -1 switches it off (default). */
+ * after_steps = -1 switches it off.  Default policy (awry_set_devices): on with after_steps = 2 for nucleotide indexes
+ * with bwt_len < 2^32 whose accelerators fit in half of the free HBM; env AWRY_VERIFY=0 disables, =N sets after_steps.
+ * It applies to reads (awry_dev_count_nt2_long, the host fast paths for L > 32); the k-mer kernel (L <= 32) uses it only
+ * after awry_set_verify_kmers(idx, 1), because on random k-mer batches the extra state costs ~15 %. */
 int awry_set_verify(awry_index_t *idx, int after_steps);
+int awry_set_verify_kmers(awry_index_t *idx, int on);
 int awry_verify_enabled(const awry_index_t *idx);
 int awry_num_devices(const awry_index_t *idx);
 

@@ -245,6 +245,8 @@ def test_dense_device_sa_does_not_change_locations(oracle, tmp_path, alphabet):
     ix.save(p)
     loaded = FmIndex.load(p).set_devices([0])
     for idx in (ix, loaded):
+        idx.set_verify(-1)          # the default policy keeps the ratio-1 dense SA resident; start from the file's samples
+        idx.set_locate_sa_ratio(0)
         assert idx.locate_sa_ratio() == 8
         for r in (1, 2, 3, 8, 16, 0):
             idx.set_locate_sa_ratio(r)
@@ -376,6 +378,7 @@ def test_seed_and_verify_in_the_kmer_kernel(oracle):
         reads = reads[~((reads == ord("N")) | (reads == ord("$"))).any(axis=1)]
         q2d = np.concatenate([reads, synth.random_queries(1001, L, 0, L)])
         want, _ = oi.parallel_count(*synth.fixed_to_csr(q2d), 4)
+        ix.set_verify_kmers(True)
         for after in (0, 1, 3):
             ix.set_verify(after)
             for k in (-1, 3, 8):
@@ -470,6 +473,7 @@ def test_fuzz_small_indexes_against_oracle(oracle):
                 want, _ = oi.parallel_count(*synth.fixed_to_csr(q2d), 2)
                 for verify in (-1, 0):
                     ix.set_verify(verify)
+                    ix.set_verify_kmers(verify >= 0)
                     assert np.array_equal(ix.count_kmers_nt2(q2d, True), want), (trial, L, verify)
                     got = ix.locate_reads_nt2(q2d)
                     wl = oi.parallel_locate(*synth.fixed_to_csr(q2d), 2)[:3]
@@ -530,3 +534,21 @@ def test_all_count_kernel_schedules_agree(oracle):
                     assert np.array_equal(ix.count_kmers_nt2(q2d, False), want), (L, nq, k, mode)
     finally:
         L_.awry_debug_set_count_kernel(-1)
+
+
+def test_default_device_policies():
+    """awry_set_devices picks the accelerators by itself: seed k = floor(log4 n) + 2, seed-and-verify structures resident
+    for reads; the k-mer kernel leaves verify off unless asked; everything can be switched off again"""
+    text, st, hd = synth.make_text(1_000_000, 0, 3, 1, 0.02)
+    ix = gpu_index(text, 0, 8, 0, st, hd)
+    assert ix.seed_kmer_len() == 11            # floor(log4(1e6)) = 9, + 2
+    assert ix.verify_enabled() and ix.locate_sa_ratio() == 1
+    assert "probe" in ix.count_schedule(31)    # 4^11 >= 3 n: two-phase
+    ix.set_seed_kmer_len(8)
+    assert ix.count_schedule(31) == "count_nt2_quad4_kernel" and ix.count_schedule(5) == "count_nt2_quad4_kernel"
+    ix.set_verify(-1)
+    ix.set_locate_sa_ratio(0)
+    assert not ix.verify_enabled() and ix.locate_sa_ratio() == 8
+    aa, st, hd = synth.make_text(50_000, 1, 4, 3)
+    ax = gpu_index(aa, 1, 8, 0, st, hd)
+    assert ax.seed_kmer_len() == 0 and not ax.verify_enabled()

@@ -341,10 +341,11 @@ void build_dense_sa(awry_index* ix, Replica& r, int ratio) {
   if (ratio <= 0) return;
   require(ix->host.bwt_len < (1ull << 32), "a dense device SA needs bwt_len < 2^32");
   const uint64_t nentries = (ix->host.bwt_len + ratio - 1) / ratio;
+  const uint64_t nsamples = (ix->host.bwt_len + ix->host.sa_ratio - 1) / ix->host.sa_ratio;  // one chain per file sample
   DevBuf<uint32_t> d(nentries);
-  const dim3 g(grid_for(r, nentries, 256)), b(256);
-  if (r.dev.alphabet == NUCLEOTIDE) hipLaunchKernelGGL(densify_sa_kernel<NUCLEOTIDE>, g, b, 0, r.stream, r.dev, (uint32_t)ratio, nentries, d.p);
-  else hipLaunchKernelGGL(densify_sa_kernel<AMINO>, g, b, 0, r.stream, r.dev, (uint32_t)ratio, nentries, d.p);
+  const dim3 g(grid_for(r, nsamples, 256, 64)), b(256);
+  if (r.dev.alphabet == NUCLEOTIDE) hipLaunchKernelGGL(densify_sa_kernel<NUCLEOTIDE>, g, b, 0, r.stream, r.dev, (uint32_t)ratio, nsamples, d.p);
+  else hipLaunchKernelGGL(densify_sa_kernel<AMINO>, g, b, 0, r.stream, r.dev, (uint32_t)ratio, nsamples, d.p);
   HIP_CHECK(hipGetLastError());
   HIP_CHECK(hipStreamSynchronize(r.stream));
   r.dense_sa = std::move(d);
@@ -1141,6 +1142,9 @@ int awry_set_verify_kmers(awry_index_t* idx, int on) {
     idx->verify_kmers_request = on != 0;
     for (auto& r : idx->reps) r->verify_kmers = on != 0;
   });
+}
+const void* awry_debug_dense_sa(const awry_index_t* idx, int slot) {
+  return idx && slot >= 0 && slot < (int)idx->reps.size() ? (const void*)idx->reps[slot]->dense_sa.p : nullptr;
 }
 int awry_verify_enabled(const awry_index_t* idx) { return idx && !idx->reps.empty() && idx->reps[0]->dev.text4 != nullptr; }
 

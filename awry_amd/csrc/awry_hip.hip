@@ -169,8 +169,17 @@ int count_kernel_mode(uint64_t bwt_len, int seed_k, bool seeded) {
 bool narrow(const HostIndex& h) { return h.bwt_len < (1ull << 32) - 512; }
 
 int default_seed_k(const HostIndex& h) {
-  if (h.alphabet != NUCLEOTIDE || !narrow(h)) return 0;
-  if (const char* e = getenv("AWRY_SEED_K")) return std::max(0, std::min(17, atoi(e)));
+  if (!narrow(h)) return 0;
+  const bool nt = h.alphabet == NUCLEOTIDE;
+  if (const char* e = getenv("AWRY_SEED_K")) return std::max(0, std::min(nt ? 17 : 7, atoi(e)));
+  if (!nt) {  // amino: 20^k ~ 1..20 x bwt_len (Swiss-Prot 9e7 -> k = 7, 10 GB), same memory rule as below
+    int k = (int)std::floor(std::log((double)h.bwt_len) / std::log(20.0)) + 1;
+    k = std::max(1, std::min(k, 7));
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
+      while (k > 1 && 8.5 * std::pow(20.0, k) > 0.7 * (double)free_b) k--;
+    return k;
+  }
   // Several table entries per suffix: k = floor(log4 bwt_len) + 2, i.e. 4^k = 4..16 x bwt_len (GRCh38: k = 17, 137 GB of
   // the 288 GB HBM; chr1: 15, 8.6 GB; E. coli: 13).  A random k-mer's entry is then empty or a singleton whose BWT
   // symbol rarely matches, so a query costs one probe plus ~0.1 steps instead of ~16 steps (27 block reads).  The
@@ -190,20 +199,27 @@ void build_seed(awry_index* ix, Replica& r, int k) {
   r.dev.seed = nullptr;
   r.dev.seed_k = 0;
   if (k <= 0) return;
-  require(ix->host.alphabet == NUCLEOTIDE && narrow(ix->host), "seed table needs a nucleotide index with bwt_len < 2^32");
-  require(k <= 17, "seed k-mer length must be <= 17");
-  const uint64_t nfinal = 1ull << (2 * k);
-  DevBuf<SeedEntry> a(nfinal), b(std::max<uint64_t>(4, nfinal >> 2));
+  require(narrow(ix->host), "seed table needs an index with bwt_len < 2^32");
+  const bool nt = ix->host.alphabet == NUCLEOTIDE;
+  const uint64_t sigma = nt ? 4 : 20;
+  require(k <= (nt ? 17 : 7), "seed k-mer length must be <= 17 (nucleotide) / 7 (amino)");
+  uint64_t nfinal = 1;
+  for (int j = 0; j < k; j++) nfinal *= sigma;
+  DevBuf<SeedEntry> a(nfinal), b(std::max<uint64_t>(sigma, nfinal / sigma));
   // level j lands in `a` when (k - j) is even, so the last level is in `a`
   SeedEntry* cur = ((k - 1) % 2 == 0) ? a.p : b.p;
-  hipLaunchKernelGGL(seed_level1_kernel, dim3(1), dim3(256), 0, r.stream, r.dev, cur);
+  if (nt) hipLaunchKernelGGL(seed_level1_kernel, dim3(1), dim3(256), 0, r.stream, r.dev, cur);
+  else hipLaunchKernelGGL(aa_seed_level1_kernel, dim3(1), dim3(256), 0, r.stream, r.dev, cur);
+  uint64_t nchild = sigma;
   for (int j = 2; j <= k; j++) {
     SeedEntry* nxt = ((k - j) % 2 == 0) ? a.p : b.p;
-    const uint64_t nchild = 1ull << (2 * j);
-    hipLaunchKernelGGL(seed_extend_kernel, dim3(grid_for(r, nchild * 4, 256)), dim3(256), 0, r.stream, r.dev, cur, nxt, nchild);
+    nchild *= sigma;
+    if (nt) hipLaunchKernelGGL(seed_extend_kernel, dim3(grid_for(r, nchild * 4, 256)), dim3(256), 0, r.stream, r.dev, cur, nxt, nchild);
+    else hipLaunchKernelGGL(aa_seed_extend_kernel, dim3(grid_for(r, nchild, 256)), dim3(256), 0, r.stream, r.dev, cur, nxt, nchild);
     cur = nxt;
   }
-  hipLaunchKernelGGL(seed_finalize_kernel, dim3(grid_for(r, nfinal, 256)), dim3(256), 0, r.stream, r.dev, a.p, nfinal);
+  if (nt) hipLaunchKernelGGL(seed_finalize_kernel, dim3(grid_for(r, nfinal, 256)), dim3(256), 0, r.stream, r.dev, a.p, nfinal);
+  else hipLaunchKernelGGL(aa_seed_finalize_kernel, dim3(grid_for(r, nfinal, 256)), dim3(256), 0, r.stream, r.dev, a.p, nfinal);
   HIP_CHECK(hipGetLastError());
   HIP_CHECK(hipStreamSynchronize(r.stream));
   r.seed = std::move(a);
@@ -879,7 +895,7 @@ int awry_set_devices(awry_index_t* idx, const int* device_ids, int n_devices) {
 int awry_set_seed_kmer_len(awry_index_t* idx, int k) {
   return guarded([&] {
     require(idx != nullptr, "null index");
-    require(k >= -1 && k <= 17, "seed k-mer length must be in -1..17");
+    require(k >= -1 && k <= 17, "seed k-mer length must be in -1..17 (amino: ..7)");
     idx->seed_k_request = k;
     for (size_t s = 0; s < idx->reps.size(); s++) {
       Replica& r = replica(idx, (int)s);

@@ -147,6 +147,27 @@ __global__ __launch_bounds__(256) void count_scalar_kernel(DevIndex ix, const ui
     if (st == Q_OK) {
       uint64_t i = e - 1;
       bool seeded = false;
+      if (A == AMINO && ix.seed && e - b >= (uint64_t)ix.seed_k) {  // last k residues all standard -> one table probe
+        const int k = ix.seed_k;
+        uint64_t sidx = 0;
+        bool std20 = true;
+        for (int j = k - 1; j >= 0; j--) {  // leftmost window letter least significant
+          const int letter = aa_letter_of_index(lut[ascii[e - k + j]]);
+          std20 = std20 && letter >= 0;
+          sidx = sidx * 20 + (uint64_t)(letter < 0 ? 0 : letter);
+        }
+        if (std20) {
+          const SeedEntry se = ix.seed[sidx];
+          const uint32_t scnt = se.cnt & AA_SEED_CNT_SAT;
+          if (scnt != AA_SEED_CNT_SAT) {
+            sp = scnt ? se.sp : 1;
+            ep = scnt ? (uint64_t)se.sp + scnt - 1 : 0;
+            i = e - k;
+            seeded = true;
+            if (scnt == 1 && i > b && (int)(se.cnt >> 27) != (int)lut[ascii[i - 1]]) { sp = 1; ep = 0; }  // BWT[sp] is not the next residue
+          }
+        }
+      }
       if (A == NUCLEOTIDE && ix.seed && e - b >= (uint64_t)ix.seed_k) {  // last k symbols all in ACGT -> one table probe
         const int k = ix.seed_k;
         uint64_t sidx = 0;
@@ -899,6 +920,45 @@ __global__ __launch_bounds__(256) void seed_finalize_kernel(DevIndex ix, SeedEnt
     SeedEntry e = table[o];
     if (e.cnt == 1u) e.cnt = 1u | ((uint32_t)symbol_at<NUCLEOTIDE>(ix, e.sp) << 29);
     else if (e.cnt >= SEED_CNT_SAT) e.cnt = SEED_CNT_SAT;
+    else continue;
+    table[o] = e;
+  }
+}
+
+// Amino seed table (20 standard residues; X and '$' are never part of a window).  Same construction as the
+// nucleotide table with sigma = 20: entry o of level j+1 = one step of parent o / 20 with letter o % 20 (the
+// leftmost window letter is the least significant digit).  Final entries pack the count in bits 0..26 (saturating
+// at AA_SEED_CNT_SAT) and, for singletons, the 5-bit symbol index of BWT[sp] in bits 27..31.
+__global__ __launch_bounds__(256) void aa_seed_level1_kernel(DevIndex ix, SeedEntry* __restrict__ out) {
+  if (blockIdx.x == 0 && threadIdx.x < 20) {
+    const int idx = aa_index_of_letter((int)threadIdx.x);
+    const uint64_t s = ix.prefix_sums[idx], e = ix.prefix_sums[idx + 1];
+    out[threadIdx.x] = SeedEntry{(uint32_t)s, (uint32_t)(e - s)};
+  }
+}
+
+__global__ __launch_bounds__(256) void aa_seed_extend_kernel(DevIndex ix, const SeedEntry* __restrict__ parent,
+                                                             SeedEntry* __restrict__ child, uint64_t nchild) {
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t o = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; o < nchild; o += stride) {
+    const SeedEntry p = parent[o / 20];
+    SeedEntry r{p.sp, 0};
+    if (p.cnt) {
+      uint64_t sp = p.sp, ep = (uint64_t)p.sp + p.cnt - 1;
+      step_scalar<AMINO>(ix, sp, ep, aa_index_of_letter((int)(o % 20)));
+      r.sp = (uint32_t)sp;
+      r.cnt = sp > ep ? 0u : (uint32_t)(ep - sp + 1);
+    }
+    child[o] = r;
+  }
+}
+
+__global__ __launch_bounds__(256) void aa_seed_finalize_kernel(DevIndex ix, SeedEntry* __restrict__ table, uint64_t nentries) {
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t o = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; o < nentries; o += stride) {
+    SeedEntry e = table[o];
+    if (e.cnt == 1u) e.cnt = 1u | ((uint32_t)symbol_at<AMINO>(ix, e.sp) << 27);
+    else if (e.cnt >= AA_SEED_CNT_SAT) e.cnt = AA_SEED_CNT_SAT;
     else continue;
     table[o] = e;
   }

@@ -72,6 +72,11 @@ constexpr uint32_t SEED_CNT_SAT = 0x1FFFFFFFu;
 AWRY_HD uint32_t seed_cnt(SeedEntry e) { return e.cnt & SEED_CNT_SAT; }
 AWRY_HD int seed_sym(SeedEntry e) { return (int)(e.cnt >> 29); }
 
+// amino seed entries: count in bits 0..26 (saturating), 5-bit symbol index of a singleton's BWT row in bits 27..31
+constexpr uint32_t AA_SEED_CNT_SAT = 0x07FFFFFFu;
+AWRY_HD int aa_index_of_letter(int l) { return l < 19 ? l + 1 : 21; }  // the 20 standard residues: 0..18 -> A..W, 19 -> Y
+AWRY_HD int aa_letter_of_index(int idx) { return idx >= 1 && idx <= 19 ? idx - 1 : (idx == 21 ? 19 : -1); }
+
 // Everything a kernel needs, passed by value (fits the kernarg segment).
 struct DevIndex {
   const uint64_t* blocks;     // nblocks * block_words(alphabet), 128-B aligned

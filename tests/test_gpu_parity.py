@@ -551,4 +551,25 @@ def test_default_device_policies():
     assert not ix.verify_enabled() and ix.locate_sa_ratio() == 8
     aa, st, hd = synth.make_text(50_000, 1, 4, 3)
     ax = gpu_index(aa, 1, 8, 0, st, hd)
-    assert ax.seed_kmer_len() == 0 and not ax.verify_enabled()
+    assert ax.seed_kmer_len() == 4 and not ax.verify_enabled()   # floor(log20(5e4)) + 1
+
+
+def test_amino_seed_table_does_not_change_counts(oracle):
+    """the 20^k amino seed table (standard residues only; X, lower case, unknown letters bypass it) against the oracle"""
+    text, st, hd = synth.make_text(300000, 1, 77, 40, 0.02)
+    ix = gpu_index(text, 1, 8, 0, st, hd)
+    oi = oracle.OracleIndex.from_text(text, 1, 8, 0, st, hd)
+    qs = []
+    for L in (1, 2, 3, 4, 5, 6, 8, 12, 20):
+        qs += [bytes(q) for q in synth.sampled_queries(text, 150, L, L, False, 1)]
+        qs += [bytes(q) for q in synth.random_queries(150, L, 1, 100 + L)]
+    qs += [b"X", b"AX", b"XA", b"MKVX", b"mkvl", b"ACDEFB", b"ZZZZ", b"AAAAAAAAAAAA"]
+    qb, qo = __import__("awry_amd").fm_index.pack_queries(qs)
+    want_c, _ = oi.parallel_count(qb, qo, 4)
+    want_l = oi.parallel_locate(qb, qo, 4)[:3]
+    assert ix.seed_kmer_len() == 5
+    for k in (-1, 0, 1, 2, 4):
+        ix.set_seed_kmer_len(k)
+        assert np.array_equal(ix.parallel_count_csr(qb, qo), want_c), k
+        got = ix.parallel_locate_csr(qb, qo)
+        assert all(np.array_equal(x, y) for x, y in zip(got, want_l)), k

@@ -802,9 +802,10 @@ static void construct(awry_index* ix, const uint8_t* text, uint64_t bwt_len, int
     const char* e = getenv("AWRY_BUILD");
     int ndev = 0;
     if (e && !strcmp(e, "host")) build_device = AWRY_BUILD_HOST;
-    else if (hipGetDeviceCount(&ndev) == hipSuccess && ndev > 0 && bwt_len < (1ull << 32) - 1 && (bwt_len >= (1u << 20) || (e && !strcmp(e, "gpu"))))
-      build_device = 0;
-    else build_device = AWRY_BUILD_HOST;
+    else if (hipGetDeviceCount(&ndev) == hipSuccess && ndev > 0 && bwt_len < (1ull << 32) - 1 && (bwt_len >= (1u << 20) || (e && !strcmp(e, "gpu")))) {
+      // the calling thread's current device (one process per GPU sets it to its own), else GPU 0
+      if (hipGetDevice(&build_device) != hipSuccess || build_device < 0 || build_device >= ndev) build_device = 0;
+    } else build_device = AWRY_BUILD_HOST;
   }
   if (build_device < 0) {
     build_from_text(ix->host, text, bwt_len, alphabet, sa_ratio, kmer_len, seq_starts, headers, nseq);

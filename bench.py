@@ -203,7 +203,7 @@ def main():
     t0 = time.time()
     text, starts, headers = synth.make_text(n_text, 0, 0xA5A50000 + 2, n_rec, n_frac)
     t1 = time.time()
-    ix = awry_amd.FmIndex.from_text(text, 0, 8, 0, starts, headers)
+    ix = awry_amd.FmIndex.from_text(text, 0, 8, 0, starts, headers, build_device=local_rank)  # each rank builds on its own GPU
     t2 = time.time()
     ix.set_devices([local_rank])
     if args.seed_k >= 0:

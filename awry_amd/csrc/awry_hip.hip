@@ -437,7 +437,7 @@ void launch_count_nt2(Replica& r, const uint64_t* d_words, uint64_t n, int L, ui
     HIP_CHECK(hipGetLastError());
     return;
   }
-  if (kmode == 3 && seeded && !(r.verify_kmers && r.dev.text4 != nullptr && r.dev.dense_ratio == 1) && n < (1ull << 32)) {
+  if (kmode == 3 && seeded && n < (1ull << 32)) {
     // two-phase: per-lane seed probes decide most queries, the quad machinery resumes the survivors
     Replica::SurvScratch* sc;
     {
@@ -457,12 +457,17 @@ void launch_count_nt2(Replica& r, const uint64_t* d_words, uint64_t n, int L, ui
     }
     const Nt2Survivors sv{sc->w.p, sc->range.p, sc->q.p, sc->count.p, per_block};
     const dim3 gp(nblk);
+    // survivors of phase 1 use seed-and-verify whenever its accelerators are resident (cheap: random batches barely
+    // reach phase 2); the single-kernel schedules use it only on request (awry_set_verify_kmers)
+    const bool vfy = r.dev.text4 != nullptr && r.dev.dense_ratio == 1;
     if (d_tally) {
       hipLaunchKernelGGL(count_nt2_probe_kernel<true>, gp, b, 0, s, r.dev, d_words, n, L, d_counts, sv, d_tally);
-      hipLaunchKernelGGL(count_nt2_resume_kernel<true>, gp, b, 0, s, r.dev, sv, L, d_counts, d_tally);
+      if (vfy) hipLaunchKernelGGL((count_nt2_resume_kernel<true, true>), gp, b, 0, s, r.dev, sv, L, d_counts, d_tally);
+      else hipLaunchKernelGGL((count_nt2_resume_kernel<true, false>), gp, b, 0, s, r.dev, sv, L, d_counts, d_tally);
     } else {
       hipLaunchKernelGGL(count_nt2_probe_kernel<false>, gp, b, 0, s, r.dev, d_words, n, L, d_counts, sv, d_tally);
-      hipLaunchKernelGGL(count_nt2_resume_kernel<false>, gp, b, 0, s, r.dev, sv, L, d_counts, d_tally);
+      if (vfy) hipLaunchKernelGGL((count_nt2_resume_kernel<false, true>), gp, b, 0, s, r.dev, sv, L, d_counts, d_tally);
+      else hipLaunchKernelGGL((count_nt2_resume_kernel<false, false>), gp, b, 0, s, r.dev, sv, L, d_counts, d_tally);
     }
     HIP_CHECK(hipGetLastError());
     return;
@@ -914,7 +919,7 @@ const char* awry_count_schedule(const awry_index_t* idx, int L) {
   const Replica& r = *idx->reps[0];
   const bool seeded = r.seed_k > 0 && r.seed_k <= L;
   int m = count_kernel_mode(r.dev.bwt_len, r.seed_k, seeded);
-  if (m == 3 && (!seeded || (r.verify_kmers && r.dev.text4 != nullptr && r.dev.dense_ratio == 1))) m = 2;
+  if (m == 3 && !seeded) m = 2;
   return names[m & 3];
 }
 

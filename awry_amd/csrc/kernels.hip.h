@@ -728,8 +728,11 @@ __global__ __launch_bounds__(256) void count_nt2_probe_kernel(DevIndex ix, const
   if (TALLY && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&tally[0], (unsigned long long)n);
 }
 
-// same grid as phase 1: block b resumes the survivors block b recorded
-template <bool TALLY>
+// same grid as phase 1: block b resumes the survivors block b recorded.  VERIFY: seed-and-verify for the survivors
+// (batches of k-mers that really occur in the text survive phase 1 wholesale; comparing their <= 31 remaining letters
+// with the text costs ~2 lines per candidate instead of one line per letter).  Random batches barely reach this kernel,
+// so the extra state costs them nothing -- which is why the k-mer path can keep verify on by default.
+template <bool TALLY, bool VERIFY>
 __global__ __launch_bounds__(256) void count_nt2_resume_kernel(DevIndex ix, Nt2Survivors sv, int L, uint64_t* __restrict__ counts,
                                                                unsigned long long* __restrict__ tally) {
   const int l = threadIdx.x & 3;
@@ -738,50 +741,83 @@ __global__ __launch_bounds__(256) void count_nt2_resume_kernel(DevIndex ix, Nt2S
   uint64_t r = threadIdx.x >> 2;  // 64 quads per block walk the block's list
   const uint64_t* __restrict__ blocks = ix.blocks;
   const int k = ix.seed_k;
+  const int verify_after = (int)ix.verify_after;
   const uint32_t cA = (uint32_t)ix.prefix_sums[1], cC = (uint32_t)ix.prefix_sums[2], cG = (uint32_t)ix.prefix_sums[3],
                  cN = (uint32_t)ix.prefix_sums[4], cT = (uint32_t)ix.prefix_sums[5], cEnd = (uint32_t)ix.prefix_sums[6];
   bool have = r < ns, fresh = true;
   uint64_t w = 0;
   uint32_t sp = 1, ep = 0, qidx = 0;
-  int i = 0;
-  uint32_t t_step = 0, t_blk = 0;
+  int i = 0, steps_done = 0;
+  int mode = 0, vj = 0;  // verify: 0 = LF steps, 1 = read SA of candidate vj, 2 = compare its text window
+  uint32_t vhits = 0, vp = 0;
+  uint32_t t_step = 0, t_blk = 0, t_vsa = 0, t_vtxt = 0;
   while (__any(have)) {
     if (have) {
-      if (fresh) {  // the record replaces the seed probe; the first step follows in the same iteration
-        w = sv.w[region + r];
-        const uint64_t rg = sv.range[region + r];
-        qidx = sv.q[region + r];
-        const uint32_t cnt = (uint32_t)(rg >> 32);
-        if (cnt == SEED_CNT_SAT) {
-          const uint32_t c = (uint32_t)(w >> (2 * (L - 1))) & 3u;
-          sp = c == 0 ? cA : (c == 1 ? cC : (c == 2 ? cG : cT));
-          ep = (c == 0 ? cC : (c == 1 ? cG : (c == 2 ? cN : cEnd))) - 1;
-          i = L - 1;
-        } else {
-          sp = (uint32_t)rg;
-          ep = sp + cnt - 1u;
-          i = L - k;
+      bool finished = false;
+      uint64_t out_count = 0;
+      if (!VERIFY || mode == 0) {
+        if (fresh) {  // the record replaces the seed probe; the first step follows in the same iteration
+          w = sv.w[region + r];
+          const uint64_t rg = sv.range[region + r];
+          qidx = sv.q[region + r];
+          const uint32_t cnt = (uint32_t)(rg >> 32);
+          if (cnt == SEED_CNT_SAT) {
+            const uint32_t c = (uint32_t)(w >> (2 * (L - 1))) & 3u;
+            sp = c == 0 ? cA : (c == 1 ? cC : (c == 2 ? cG : cT));
+            ep = (c == 0 ? cC : (c == 1 ? cG : (c == 2 ? cN : cEnd))) - 1;
+            i = L - 1;
+          } else {
+            sp = (uint32_t)rg;
+            ep = sp + cnt - 1u;
+            i = L - k;
+          }
+          steps_done = 0;
+          fresh = false;
         }
-        fresh = false;
+        if (i > 0 && sp <= ep) {
+          i--;
+          const uint32_t c = (uint32_t)(w >> (2 * i)) & 3u;
+          const uint32_t cl = c == 0 ? cA : (c == 1 ? cC : (c == 2 ? cG : cT));
+          if (TALLY) { t_step++; t_blk += ((sp - 1) >> 8) == (ep >> 8) ? 1u : 2u; }
+          quad_step(blocks, cl, sp, ep, c, l);
+          steps_done++;
+        }
+        if (sp > ep || i == 0) {
+          finished = true;
+          out_count = sp > ep ? 0ull : (uint64_t)(ep - sp) + 1ull;
+        } else if (VERIFY) {
+          const uint32_t cnt = ep - sp + 1u;
+          if (cnt <= 8u && (int)(3u * cnt) <= i && steps_done >= verify_after) { mode = 1; vj = 0; vhits = 0; }
+        }
+      } else if (mode == 1) {
+        vp = ix.dense_sa[sp + (uint32_t)vj];
+        if (TALLY) t_vsa++;
+        if (vp >= (uint32_t)i) mode = 2;
+        else vj++;
+      } else {
+        const uint32_t bad = quad_sum(verify_part(ix.text4, (uint64_t)vp - (uint64_t)i, i, 0, l, w));
+        if (TALLY) t_vtxt++;
+        if (!bad) vhits++;
+        vj++;
+        mode = 1;
       }
-      if (i > 0 && sp <= ep) {
-        i--;
-        const uint32_t c = (uint32_t)(w >> (2 * i)) & 3u;
-        const uint32_t cl = c == 0 ? cA : (c == 1 ? cC : (c == 2 ? cG : cT));
-        if (TALLY) { t_step++; t_blk += ((sp - 1) >> 8) == (ep >> 8) ? 1u : 2u; }
-        quad_step(blocks, cl, sp, ep, c, l);
-      }
-      if (sp > ep || i == 0) {
-        if (l == 0) counts[qidx] = sp > ep ? 0ull : (uint64_t)(ep - sp) + 1ull;
+      if (VERIFY && mode == 1 && vj > (int)(ep - sp)) { finished = true; out_count = vhits; }
+      if (finished) {
+        if (l == 0) counts[qidx] = out_count;
         r += 64;
         have = r < ns;
         fresh = true;
+        mode = 0;
       }
     }
   }
   if (TALLY && l == 0) {
     atomicAdd(&tally[1], (unsigned long long)t_step);
     atomicAdd(&tally[2], (unsigned long long)t_blk);
+    if (VERIFY) {
+      atomicAdd(&tally[3], (unsigned long long)t_vsa);
+      atomicAdd(&tally[4], (unsigned long long)t_vtxt);
+    }
   }
 }
 

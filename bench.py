@@ -257,8 +257,10 @@ def main():
     for i in range(K):
         ix.dev_count_nt2_tally(batches[(W + i) % n_batches].data_ptr(), nq, L, counts.data_ptr(), tally.data_ptr(), True, stream, 0)
     torch.cuda.synchronize()
-    probes, steps_exec, blocks = [int(x) / K for x in tally.cpu().tolist()[:3]]
-    alg_bytes = 16.0 * probes + 104.0 * blocks + nq * (8.0 + 8.0)  # probe 16 B, block 104 B, query 8 B, result 8 B
+    probes, steps_exec, blocks, vsa, vtxt = [int(x) / K for x in tally.cpu().tolist()[:5]]
+    # probe 16 B, block 104 B, query 8 B, result 8 B; seed-and-verify (survivors only): 8 B per SA read
+    # and the <= 8 B text window of the remaining letters
+    alg_bytes = 16.0 * probes + 104.0 * blocks + nq * (8.0 + 8.0) + 8.0 * vsa + 8.0 * vtxt
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
     if world > 1:
@@ -280,7 +282,8 @@ def main():
         "roofline": {"bound": "hbm", "kernel": ix.count_schedule(L), "achieved": alg_bytes / (kernel_ms * 1e-3) / 1e9,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg_bytes / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                      "traffic": None, "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": alg_bytes,
-                     "census_per_launch": {"seed_probes": probes, "steps": steps_exec, "block_reads": blocks}},
+                     "census_per_launch": {"seed_probes": probes, "steps": steps_exec, "block_reads": blocks,
+                                           "verify_sa_reads": vsa, "verify_text_windows": vtxt}},
     }
 
     # HBM traffic per launch from the committed rocprofv3 PMC passes of this exact configuration (null otherwise)
@@ -346,10 +349,10 @@ def main():
             extra["present_queries"] = {"queries": ns, "queries_per_s": ns / (ms * 1e-3), "kernel_ms": ms,
                                         "achieved_GBs": ab / (ms * 1e-3) / 1e9, "frac": ab / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                         "steps_per_query": s3 / ns}
-            # the same present k-mers with seed-and-verify (dense SA + 4-bit text resident in HBM)
+            # the same present k-mers by LF steps only (seed-and-verify accelerators dropped): the contrast to the default
             want_present = counts[:ns].clone()
-            ix.set_verify(2)
-            ix.set_verify_kmers(True)
+            had_verify = ix.verify_enabled()
+            ix.set_verify(-1)
             for _ in range(2):
                 ix.dev_count_nt2(d_words.data_ptr(), ns, L, counts.data_ptr(), True, stream, 0)
             e0.record()
@@ -359,15 +362,10 @@ def main():
             torch.cuda.synchronize()
             msv = e0.elapsed_time(e1) / 5
             assert bool(torch.equal(counts[:ns], want_present)), "seed-and-verify changed a count"
-            ix.dev_count_nt2(batches[0].data_ptr(), nq, L, counts.data_ptr(), True, stream, 0)  # random batch under verify
-            e0.record()
-            for i in range(5):
-                ix.dev_count_nt2(batches[i % n_batches].data_ptr(), nq, L, counts.data_ptr(), True, stream, 0)
-            e1.record()
-            torch.cuda.synchronize()
-            extra["seed_and_verify"] = {"present_queries_per_s": ns / (msv * 1e-3), "present_kernel_ms": msv,
-                                        "random_queries_per_s": nq / (e0.elapsed_time(e1) / 5 * 1e-3), "identical_counts": True}
-            ix.set_verify_kmers(False)
+            extra["present_queries"]["seed_and_verify"] = bool(had_verify)
+            extra["present_queries_lf_steps_only"] = {"queries_per_s": ns / (msv * 1e-3), "kernel_ms": msv, "identical_counts": True}
+            if had_verify:
+                ix.set_verify(2)
             # ASCII boundary with on-device packing in the timed region (31 B/query read instead of 8 B)
             na = min(nq, 5_000_000)
             asc = torch.from_numpy(unpack_nt2(batches[0][:na].cpu().numpy().view(np.uint64), L).reshape(-1)).to(dev)

@@ -82,6 +82,7 @@ struct DevBuf {  // RAII device allocation on the current device
 struct Replica {
   int device = -1;
   hipStream_t stream = nullptr;
+  hipStream_t lane_stream[2] = {nullptr, nullptr};  // the two pipeline lanes of the packed host path
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   DevBuf<uint64_t> blocks, sa_words, seq_starts;
   DevBuf<SeedEntry> seed;
@@ -102,6 +103,7 @@ struct Replica {
     if (device >= 0) {
       (void)hipSetDevice(device);
       if (stream) (void)hipStreamDestroy(stream);
+      for (auto& ls : lane_stream) if (ls) (void)hipStreamDestroy(ls);
       if (ev0) (void)hipEventDestroy(ev0);
       if (ev1) (void)hipEventDestroy(ev1);
       blocks.reset(); sa_words.reset(); seq_starts.reset(); seed.reset(); chunk_counters.reset(); dense_sa.reset(); text4.reset();
@@ -243,6 +245,7 @@ std::unique_ptr<Replica> make_replica(awry_index* ix, int device) {
   HIP_CHECK(hipGetDeviceProperties(&prop, device));
   r->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   HIP_CHECK(hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking));
+  for (auto& ls : r->lane_stream) HIP_CHECK(hipStreamCreateWithFlags(&ls, hipStreamNonBlocking));
   HIP_CHECK(hipEventCreate(&r->ev0));
   HIP_CHECK(hipEventCreate(&r->ev1));
   const HostIndex& h = ix->host;
@@ -580,8 +583,7 @@ struct PackedLane {
   unsigned long long* h_bad = nullptr;  // pinned
   Shard chunk{0, 0};
   bool busy = false;
-  ~PackedLane() {
-    if (s) (void)hipStreamDestroy(s);
+  ~PackedLane() {  // the stream belongs to the replica
     if (done) (void)hipEventDestroy(done);
     if (h_bad) (void)hipHostFree(h_bad);
   }
@@ -612,8 +614,9 @@ void count_shard_packed(Replica& r, const uint8_t* qbytes, const uint64_t* qoff,
     if (*ln.h_bad) redo.push_back(ln.chunk);
     ln.busy = false;
   };
-  for (auto& ln : lanes) {
-    HIP_CHECK(hipStreamCreateWithFlags(&ln.s, hipStreamNonBlocking));
+  for (int li = 0; li < 2; li++) {
+    PackedLane& ln = lanes[li];
+    ln.s = r.lane_stream[li];
     HIP_CHECK(hipEventCreateWithFlags(&ln.done, hipEventDisableTiming));
     HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&ln.h_bad), 8, hipHostMallocDefault));
     const uint64_t cap = std::min<uint64_t>(CH, sh.hi - sh.lo);

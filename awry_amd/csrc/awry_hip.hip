@@ -6,6 +6,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -79,10 +80,28 @@ struct DevBuf {  // RAII device allocation on the current device
   void reset() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
 };
 
+// one pipeline lane of the packed host path (count_shard_packed): buffers persist in the replica and only grow
+struct PackedLane {
+  hipStream_t s = nullptr;  // owned by the replica
+  hipEvent_t done = nullptr;
+  DevBuf<uint8_t> ascii;
+  DevBuf<uint64_t> words, counts;
+  DevBuf<unsigned long long> bad;
+  unsigned long long* h_bad = nullptr;  // pinned
+  uint64_t chunk_lo = 0, chunk_hi = 0;
+  bool busy = false;
+  ~PackedLane() {
+    if (done) (void)hipEventDestroy(done);
+    if (h_bad) (void)hipHostFree(h_bad);
+  }
+};
+
 struct Replica {
   int device = -1;
   hipStream_t stream = nullptr;
   hipStream_t lane_stream[2] = {nullptr, nullptr};  // the two pipeline lanes of the packed host path
+  PackedLane lanes[2];
+  std::mutex lane_mu;  // one packed host call at a time per replica
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   DevBuf<uint64_t> blocks, sa_words, seq_starts;
   DevBuf<SeedEntry> seed;
@@ -574,28 +593,26 @@ struct HostPin {
 // letters in ACGT.  Chunks flow through two stream lanes (H2D ASCII -> pack on device -> packed quad kernel ->
 // D2H counts) so transfers overlap kernels; no per-query offsets cross PCIe.  A chunk that turns out to hold
 // other bytes (N, IUPAC codes, '$' ...) is re-run through the generic kernel, so results never depend on the path.
-struct PackedLane {
-  hipStream_t s = nullptr;
-  hipEvent_t done = nullptr;
-  DevBuf<uint8_t> ascii;
-  DevBuf<uint64_t> words, counts;
-  DevBuf<unsigned long long> bad;
-  unsigned long long* h_bad = nullptr;  // pinned
-  Shard chunk{0, 0};
-  bool busy = false;
-  ~PackedLane() {  // the stream belongs to the replica
-    if (done) (void)hipEventDestroy(done);
-    if (h_bad) (void)hipHostFree(h_bad);
-  }
-};
-
+// The lane buffers persist in the replica (PackedLane), so a call costs no device allocation.
 bool shard_fixed_length(const uint64_t* qoff, Shard sh, uint64_t& L) {
   if (sh.hi <= sh.lo) return false;
   L = qoff[sh.lo + 1] - qoff[sh.lo];
   if (L == 0 || L > 4096) return false;
-  for (uint64_t i = sh.lo; i < sh.hi; i++)
-    if (qoff[i + 1] - qoff[i] != L) return false;
-  return true;
+  const uint64_t n = sh.hi - sh.lo;
+  auto scan = [&](uint64_t lo, uint64_t hi) {
+    uint64_t diff = 0;  // branch-free so the loop vectorises
+    for (uint64_t i = lo; i < hi; i++) diff |= (qoff[i + 1] - qoff[i]) ^ L;
+    return diff == 0;
+  };
+  if (!scan(sh.lo, sh.lo + std::min<uint64_t>(n, 4096))) return false;  // ragged batches leave here
+  const unsigned T = n >= (2u << 20) ? std::min(8u, std::max(1u, std::thread::hardware_concurrency())) : 1;
+  if (T == 1) return scan(sh.lo, sh.hi);
+  std::atomic<bool> ok{true};
+  std::vector<std::thread> th;
+  for (unsigned t = 0; t < T; t++)
+    th.emplace_back([&, t] { if (!scan(sh.lo + n * t / T, sh.lo + n * (t + 1) / T)) ok = false; });
+  for (auto& x : th) x.join();
+  return ok;
 }
 
 void launch_count_nt2(Replica& r, const uint64_t* d_words, uint64_t n, int L, uint64_t* d_counts, bool use_seed, hipStream_t s,
@@ -603,46 +620,77 @@ void launch_count_nt2(Replica& r, const uint64_t* d_words, uint64_t n, int L, ui
 void count_shard_generic(Replica& r, const uint8_t* qbytes, const uint64_t* qoff, Shard sh, uint64_t* counts_out);
 
 void count_shard_packed(Replica& r, const uint8_t* qbytes, const uint64_t* qoff, Shard sh, uint64_t L, uint64_t* counts_out) {
-  const uint64_t CH = 4u << 20;  // queries per chunk
+  // queries per chunk: at most 4M, and at most 256 MiB of ASCII per lane
+  const uint64_t CH = std::max<uint64_t>(1u << 16, std::min<uint64_t>(4u << 20, (256ull << 20) / L));
   const int W = (int)((L + 31) / 32);
-  HostPin pin_in(qbytes + qoff[sh.lo], (sh.hi - sh.lo) * L), pin_out(counts_out + sh.lo, (sh.hi - sh.lo) * 8);
-  PackedLane lanes[2];
+  static const bool trace = getenv("AWRY_TRACE_HOST") != nullptr;
+  auto now = [] { return std::chrono::steady_clock::now(); };
+  auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+  std::lock_guard<std::mutex> lane_lock(r.lane_mu);
+  const auto t0 = now();
+  // the output range is pinned by a helper thread (first-touch page faults of a fresh buffer dominate it) while
+  // this thread pins the input and starts the first chunk; joined before the first D2H is queued
+  std::unique_ptr<HostPin> pin_out;
+  std::thread pin_out_thread([&] {
+    (void)hipSetDevice(r.device);
+    pin_out.reset(new HostPin(counts_out + sh.lo, (sh.hi - sh.lo) * 8));
+  });
+  struct Joiner {
+    std::thread& t;
+    ~Joiner() { if (t.joinable()) t.join(); }
+  } joiner{pin_out_thread};
+  HostPin pin_in(qbytes + qoff[sh.lo], (sh.hi - sh.lo) * L);
+  const auto t1 = now();
+  PackedLane* lanes = r.lanes;
   std::vector<Shard> redo;
   auto retire = [&](PackedLane& ln) {
     if (!ln.busy) return;
-    HIP_CHECK(hipEventSynchronize(ln.done));
-    if (*ln.h_bad) redo.push_back(ln.chunk);
     ln.busy = false;
+    HIP_CHECK(hipEventSynchronize(ln.done));
+    if (*ln.h_bad) redo.push_back(Shard{ln.chunk_lo, ln.chunk_hi});
   };
+  // every exit, normal or not, leaves the lanes idle before the host ranges are unpinned
+  struct Drain {
+    Replica& r;
+    ~Drain() {
+      for (int li = 0; li < 2; li++)
+        if (r.lanes[li].busy) { (void)hipStreamSynchronize(r.lane_stream[li]); r.lanes[li].busy = false; }
+    }
+  } drain{r};
   for (int li = 0; li < 2; li++) {
     PackedLane& ln = lanes[li];
     ln.s = r.lane_stream[li];
-    HIP_CHECK(hipEventCreateWithFlags(&ln.done, hipEventDisableTiming));
-    HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&ln.h_bad), 8, hipHostMallocDefault));
+    if (!ln.done) HIP_CHECK(hipEventCreateWithFlags(&ln.done, hipEventDisableTiming));
+    if (!ln.h_bad) HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&ln.h_bad), 8, hipHostMallocDefault));
     const uint64_t cap = std::min<uint64_t>(CH, sh.hi - sh.lo);
-    ln.ascii.alloc(cap * L + 16);
-    ln.words.alloc(cap * W);
-    ln.counts.alloc(cap);
-    ln.bad.alloc(1);
+    if (ln.ascii.n < cap * L + 16) ln.ascii.alloc(cap * L + 16);
+    if (ln.words.n < cap * W) ln.words.alloc(cap * W);
+    if (ln.counts.n < cap) ln.counts.alloc(cap);
+    if (!ln.bad.p) ln.bad.alloc(1);
   }
+  const auto t2 = now();
   int which = 0;
   for (uint64_t lo = sh.lo; lo < sh.hi; lo += CH, which ^= 1) {
     PackedLane& ln = lanes[which];
     retire(ln);
     const uint64_t hi = std::min(sh.hi, lo + CH), n = hi - lo;
-    ln.chunk = Shard{lo, hi};
+    ln.chunk_lo = lo;
+    ln.chunk_hi = hi;
     HIP_CHECK(hipMemcpyAsync(ln.ascii.p, qbytes + qoff[lo], n * L, hipMemcpyHostToDevice, ln.s));
     HIP_CHECK(hipMemsetAsync(ln.bad.p, 0, 8, ln.s));
     hipLaunchKernelGGL(pack_nt2_kernel, dim3(grid_for(r, n, 256)), dim3(256), 0, ln.s, ln.ascii.p, n, (int)L, ln.words.p, ln.bad.p);
     HIP_CHECK(hipGetLastError());
     if (L <= 32) launch_count_nt2(r, ln.words.p, n, (int)L, ln.counts.p, true, ln.s, nullptr);
     else launch_count_nt2_long(r, ln.words.p, n, (int)L, ln.counts.p, nullptr, true, ln.s);
+    if (pin_out_thread.joinable()) pin_out_thread.join();
     HIP_CHECK(hipMemcpyAsync(counts_out + lo, ln.counts.p, n * 8, hipMemcpyDeviceToHost, ln.s));
     HIP_CHECK(hipMemcpyAsync(ln.h_bad, ln.bad.p, 8, hipMemcpyDeviceToHost, ln.s));
     HIP_CHECK(hipEventRecord(ln.done, ln.s));
     ln.busy = true;
   }
-  for (auto& ln : lanes) retire(ln);
+  for (int li = 0; li < 2; li++) retire(lanes[li]);
+  if (trace) fprintf(stderr, "[awry] packed shard %llu queries: pin %.2f ms, lane setup %.2f ms, pipeline %.2f ms\n",
+                     (unsigned long long)(sh.hi - sh.lo), ms(t0, t1), ms(t1, t2), ms(t2, now()));
   for (Shard c : redo) count_shard_generic(r, qbytes, qoff, c, counts_out);  // also raises INVALID_QUERY where due
 }
 
@@ -650,7 +698,11 @@ void count_shard(Replica& r, const uint8_t* qbytes, const uint64_t* qoff, Shard 
   HIP_CHECK(hipSetDevice(r.device));
   uint64_t L = 0;
   static const bool no_fast = getenv("AWRY_HOST_PATH") && !strcmp(getenv("AWRY_HOST_PATH"), "generic");
-  if (!no_fast && r.dev.alphabet == NUCLEOTIDE && r.dev.bwt_len < (1ull << 32) - 512 && shard_fixed_length(qoff, sh, L)) {
+  const auto t0 = std::chrono::steady_clock::now();
+  const bool fixed = !no_fast && r.dev.alphabet == NUCLEOTIDE && r.dev.bwt_len < (1ull << 32) - 512 && shard_fixed_length(qoff, sh, L);
+  if (getenv("AWRY_TRACE_HOST"))
+    fprintf(stderr, "[awry] fixed-length scan %.2f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+  if (fixed) {
     count_shard_packed(r, qbytes, qoff, sh, L, counts_out);
     return;
   }
@@ -936,7 +988,10 @@ int awry_count_batch(awry_index_t* idx, const uint8_t* qbytes, const uint64_t* q
   return guarded([&] {
     require(idx && qoff && (counts_out || n == 0), "null argument");
     require(qbytes || qoff[n] == qoff[0], "null query bytes");
+    const auto t0 = std::chrono::steady_clock::now();
     for_each_replica(idx, n, [&](Replica& r, Shard sh, int) { count_shard(r, qbytes, qoff, sh, counts_out); });
+    if (getenv("AWRY_TRACE_HOST"))
+      fprintf(stderr, "[awry] awry_count_batch %.2f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
   });
 }
 

@@ -482,15 +482,14 @@ void launch_count_nt2(Replica& r, const uint64_t* d_words, uint64_t n, int L, ui
     // survivors of phase 1 use seed-and-verify whenever its accelerators are resident (cheap: random batches barely
     // reach phase 2); the single-kernel schedules use it only on request (awry_set_verify_kmers)
     const bool vfy = r.dev.text4 != nullptr && r.dev.dense_ratio == 1;
-    if (d_tally) {
-      hipLaunchKernelGGL(count_nt2_probe_kernel<true>, gp, b, 0, s, r.dev, d_words, n, L, d_counts, sv, d_tally);
-      if (vfy) hipLaunchKernelGGL((count_nt2_resume_kernel<true, true>), gp, b, 0, s, r.dev, sv, L, d_counts, d_tally);
-      else hipLaunchKernelGGL((count_nt2_resume_kernel<true, false>), gp, b, 0, s, r.dev, sv, L, d_counts, d_tally);
-    } else {
-      hipLaunchKernelGGL(count_nt2_probe_kernel<false>, gp, b, 0, s, r.dev, d_words, n, L, d_counts, sv, d_tally);
-      if (vfy) hipLaunchKernelGGL((count_nt2_resume_kernel<false, true>), gp, b, 0, s, r.dev, sv, L, d_counts, d_tally);
-      else hipLaunchKernelGGL((count_nt2_resume_kernel<false, false>), gp, b, 0, s, r.dev, sv, L, d_counts, d_tally);
-    }
+#define AWRY_LAUNCH_TWO_PHASE(T, V)                                                                                 \
+  do {                                                                                                             \
+    hipLaunchKernelGGL((count_nt2_probe_kernel<T, V>), gp, b, 0, s, r.dev, d_words, n, L, d_counts, sv, d_tally);  \
+    hipLaunchKernelGGL((count_nt2_resume_kernel<T, V>), gp, b, 0, s, r.dev, sv, L, d_counts, d_tally);             \
+  } while (0)
+    if (d_tally) { if (vfy) AWRY_LAUNCH_TWO_PHASE(true, true); else AWRY_LAUNCH_TWO_PHASE(true, false); }
+    else { if (vfy) AWRY_LAUNCH_TWO_PHASE(false, true); else AWRY_LAUNCH_TWO_PHASE(false, false); }
+#undef AWRY_LAUNCH_TWO_PHASE
     HIP_CHECK(hipGetLastError());
     return;
   }

@@ -494,6 +494,13 @@ __global__ __launch_bounds__(256) void count_nt2_quad_kernel(DevIndex ix, const 
   }
 }
 
+// Seed-and-verify switch: compare the remaining i letters with the text instead of taking i more LF steps?
+// A single candidate is verified at once (2 lines: SA + text, against one line per remaining letter); a range of
+// 2..8 rows first takes `after` LF steps, which usually thin it out at one line each.
+__device__ __forceinline__ bool verify_now(uint32_t cnt, int i, int steps_done, int after) {
+  return cnt <= 8u && (int)(3u * cnt) <= i && (cnt == 1u || steps_done >= after);
+}
+
 // 16 packed 2-bit letters (low 32 bits of x) -> 16 nibbles holding the same letters
 __device__ __forceinline__ uint64_t spread_letters16(uint64_t x) {
   x &= 0xFFFFFFFFull;
@@ -604,7 +611,7 @@ __global__ __launch_bounds__(256) void count_nt2_quad4_kernel(DevIndex ix, const
           out_count = sp > ep ? 0ull : (uint64_t)(ep - sp) + 1ull;
         } else if (VERIFY) {
           const uint32_t cnt = ep - sp + 1u;
-          if (cnt <= 8u && (int)(3u * cnt) <= i && steps_done >= verify_after) { mode = 1; vj = 0; vhits = 0; }
+          if (verify_now(cnt, i, steps_done, verify_after)) { mode = 1; vj = 0; vhits = 0; }
         }
       } else if (mode == 1) {
         vp = ix.dense_sa[sp + (uint32_t)vj];
@@ -662,20 +669,55 @@ struct Nt2Survivors {
   uint64_t cap;                // slots per block
 };
 
-template <bool TALLY>
+// VERIFY (dense SA + 4-bit text resident): a probed singleton whose BWT symbol matched is not handed to phase 2 but
+// settled here, one candidate per LANE: SA[sp] gives its text position, the L - k letters in front of it are one
+// <= 16-B text window.  Such queries wait in a wave-private LDS queue until 64 are pending, so the two dependent loads
+// are always issued by full waves (a batch of k-mers that occur in the text takes this path wholesale; a random
+// batch fills a queue once in a while and pays nothing otherwise).
+template <bool TALLY, bool VERIFY>
 __global__ __launch_bounds__(256) void count_nt2_probe_kernel(DevIndex ix, const uint64_t* __restrict__ queries, uint64_t n, int L,
                                                               uint64_t* __restrict__ counts, Nt2Survivors sv,
                                                               unsigned long long* __restrict__ tally) {
   __shared__ unsigned int s_count;  // a single device-wide list head would serialise ~150 k wave-level atomics (1.8 ms)
+  constexpr int VQ = 192;                          // queue slots per wave: drained 128 at a time, two per lane
+  __shared__ uint64_t s_vw[VERIFY ? 4 : 1][VQ];   // per-wave verify queue: query word,
+  __shared__ uint32_t s_vsp[VERIFY ? 4 : 1][VQ];  //   candidate row,
+  __shared__ uint32_t s_vq[VERIFY ? 4 : 1][VQ];   //   query index
   if (threadIdx.x == 0) s_count = 0;
   __syncthreads();
-  const int lane = threadIdx.x & 63;
+  const int lane = threadIdx.x & 63, wv_id = threadIdx.x >> 6;
   const SeedEntry* __restrict__ seed = ix.seed;
   const int k = ix.seed_k, i0 = L - k, kshift = 2 * (L - k);
   const uint64_t kmask = (1ull << (2 * k)) - 1;
   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
   const uint64_t lane_lt = (1ull << lane) - 1;
   const uint64_t region = (uint64_t)blockIdx.x * sv.cap;
+  const bool verify = VERIFY && i0 >= 3;
+  int vcount = 0;  // wave-uniform fill of this wave's queue
+  uint32_t t_vsa = 0, t_vtxt = 0;
+  auto drain = [&](int base, int cnt) {  // entries [base, base + cnt) of the queue, cnt <= 128: two per lane
+    uint64_t w[2];
+    uint32_t q[2], vp[2];
+    bool on[2];
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      const int s = base + lane + 64 * h;
+      on[h] = lane + 64 * h < cnt;
+      w[h] = on[h] ? s_vw[VERIFY ? wv_id : 0][s] : 0;
+      q[h] = on[h] ? s_vq[VERIFY ? wv_id : 0][s] : 0;
+      vp[h] = on[h] ? ix.dense_sa[s_vsp[VERIFY ? wv_id : 0][s]] : 0;
+      if (TALLY && on[h]) t_vsa++;
+    }
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      uint64_t value = 0;
+      if (on[h] && vp[h] >= (uint32_t)i0) {  // else the suffix starts too close to the text's beginning
+        if (TALLY) t_vtxt++;
+        value = verify_part(ix.text4, (uint64_t)vp[h] - (uint64_t)i0, i0, 0, 0, w[h]) ? 0ull : 1ull;
+      }
+      if (on[h]) counts[q[h]] = value;
+    }
+  };
   // the trip count is wave-uniform (ballots and the wave-level atomic below need every lane of the wave)
   constexpr int NQ = 4;  // queries in flight per lane: all NQ words, then all NQ seed probes, are issued before any is used
   for (uint64_t wbase = (uint64_t)blockIdx.x * blockDim.x + (threadIdx.x & ~63u); wbase < n; wbase += NQ * stride) {
@@ -697,7 +739,7 @@ __global__ __launch_bounds__(256) void count_nt2_probe_kernel(DevIndex ix, const
       const uint64_t q = qv[h], w = wv[h];
       const SeedEntry e = ev[h];
       const uint32_t cnt = seed_cnt(e);
-      bool survivor = false;
+      bool survivor = false, queued = false;
       uint64_t value = 0;
       if (valid) {
         if (cnt == SEED_CNT_SAT) survivor = true;
@@ -706,8 +748,27 @@ __global__ __launch_bounds__(256) void count_nt2_probe_kernel(DevIndex ix, const
         else if (cnt == 1u) {
           const uint32_t nc = (uint32_t)(w >> (2 * (i0 - 1))) & 3u;
           survivor = seed_sym(e) == (int)(nc == 3u ? 5u : nc + 1u);  // else BWT[sp] is not the next letter: absent
+          if (verify && survivor) { queued = true; survivor = false; }
         } else survivor = true;
-        counts[q] = value;  // coalesced; survivors are overwritten by phase 2
+        if (!queued) counts[q] = value;  // coalesced; survivors are overwritten by phase 2
+      }
+      if (VERIFY) {
+        const uint64_t qm = __ballot(queued);
+        if (qm) {
+          if (queued) {
+            const int s = vcount + (int)__popcll(qm & lane_lt);
+            s_vw[wv_id][s] = w;
+            s_vsp[wv_id][s] = e.sp;
+            s_vq[wv_id][s] = (uint32_t)q;
+          }
+          vcount += (int)__popcll(qm);
+          __builtin_amdgcn_wave_barrier();
+          if (vcount >= 128) {
+            vcount -= 128;
+            drain(vcount, 128);
+            __builtin_amdgcn_wave_barrier();
+          }
+        }
       }
       const uint64_t sm = __ballot(survivor);
       if (sm) {
@@ -723,9 +784,16 @@ __global__ __launch_bounds__(256) void count_nt2_probe_kernel(DevIndex ix, const
       }
     }
   }
+  if (VERIFY && vcount > 0) drain(0, vcount);
   __syncthreads();
   if (threadIdx.x == 0) sv.count[blockIdx.x] = s_count;
-  if (TALLY && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&tally[0], (unsigned long long)n);
+  if (TALLY) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&tally[0], (unsigned long long)n);
+    if (VERIFY && (t_vsa | t_vtxt)) {
+      atomicAdd(&tally[3], (unsigned long long)t_vsa);
+      atomicAdd(&tally[4], (unsigned long long)t_vtxt);
+    }
+  }
 }
 
 // same grid as phase 1: block b resumes the survivors block b recorded.  VERIFY: seed-and-verify for the survivors
@@ -774,7 +842,9 @@ __global__ __launch_bounds__(256) void count_nt2_resume_kernel(DevIndex ix, Nt2S
           steps_done = 0;
           fresh = false;
         }
-        if (i > 0 && sp <= ep) {
+        // a probed singleton (its BWT symbol already matched the next letter) goes straight to the text
+        const bool skip_step = VERIFY && i > 0 && sp <= ep && verify_now(ep - sp + 1u, i, steps_done, verify_after);
+        if (i > 0 && sp <= ep && !skip_step) {
           i--;
           const uint32_t c = (uint32_t)(w >> (2 * i)) & 3u;
           const uint32_t cl = c == 0 ? cA : (c == 1 ? cC : (c == 2 ? cG : cT));
@@ -787,7 +857,7 @@ __global__ __launch_bounds__(256) void count_nt2_resume_kernel(DevIndex ix, Nt2S
           out_count = sp > ep ? 0ull : (uint64_t)(ep - sp) + 1ull;
         } else if (VERIFY) {
           const uint32_t cnt = ep - sp + 1u;
-          if (cnt <= 8u && (int)(3u * cnt) <= i && steps_done >= verify_after) { mode = 1; vj = 0; vhits = 0; }
+          if (verify_now(cnt, i, steps_done, verify_after)) { mode = 1; vj = 0; vhits = 0; }
         }
       } else if (mode == 1) {
         vp = ix.dense_sa[sp + (uint32_t)vj];
@@ -1098,7 +1168,7 @@ __global__ __launch_bounds__(256) void count_nt2_reads_kernel(DevIndex ix, const
           out_rs = (RS_PLAIN << RS_MODE_SHIFT) | sp;
         } else if (VERIFY) {
           const uint32_t cnt = ep - sp + 1u;
-          if (cnt <= 8u && (int)(3u * cnt) <= i && steps_done >= verify_after && i < 65536) { mode = 1; vj = 0; vmask = 0; }
+          if (verify_now(cnt, i, steps_done, verify_after) && i < 65536) { mode = 1; vj = 0; vmask = 0; }
         }
       } else if (mode == 1) {  // text position of candidate row sp + vj
         vp = dense[sp + (uint32_t)vj];

@@ -419,11 +419,14 @@ class FmIndex:
         return float(ms.value)
 
     # convenience: count packed-able fixed-length ACGT k-mers given as uint8[n, L] through the hot kernel
-    def count_kmers_nt2(self, q2d: np.ndarray, use_seed=True, slot=0) -> np.ndarray:
+    def count_kmers_nt2(self, q2d: np.ndarray, use_seed=True, slot=0, tally=False):
+        """fixed-length ACGT k-mers uint8[n, L <= 32] through the packed kernel -> counts; tally=True also returns the
+        kernel's census uint64[5] = (seed probes, LF steps, ranked blocks, verify SA reads, verify text windows)"""
         q2d = np.ascontiguousarray(q2d, dtype=np.uint8)
         n, L = q2d.shape
         d_ascii = self.dev_upload(q2d.reshape(-1), slot)
         d_words, d_counts, d_bad = self.dev_malloc(8 * n, slot), self.dev_malloc(8 * n, slot), self.dev_malloc(8, slot)
+        d_tally = self.dev_malloc(40, slot) if tally else None
         try:
             self.dev_memset(d_bad, 0, 8, slot)
             self.dev_pack_nt2(d_ascii, n, L, d_words, d_bad, None, slot)
@@ -431,9 +434,15 @@ class FmIndex:
             bad = int(self.dev_download(d_bad, (1,), np.uint64, slot)[0])
             if bad:
                 raise AwryError(ERR_INVALID_QUERY, "%d queries contain bytes outside ACGT; use parallel_count" % bad)
-            self.dev_count_nt2(d_words, n, L, d_counts, use_seed, None, slot)
+            if tally:
+                self.dev_memset(d_tally, 0, 40, slot)
+                self.dev_count_nt2_tally(d_words, n, L, d_counts, d_tally, use_seed, None, slot)
+            else:
+                self.dev_count_nt2(d_words, n, L, d_counts, use_seed, None, slot)
             self.dev_synchronize(slot)
-            return self.dev_download(d_counts, (n,), np.uint64, slot)
+            counts = self.dev_download(d_counts, (n,), np.uint64, slot)
+            return (counts, self.dev_download(d_tally, (5,), np.uint64, slot)) if tally else counts
         finally:
-            for p in (d_ascii, d_words, d_counts, d_bad):
-                self.dev_free(p, slot)
+            for p in (d_ascii, d_words, d_counts, d_bad, d_tally):
+                if p is not None:
+                    self.dev_free(p, slot)

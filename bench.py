@@ -301,6 +301,20 @@ def main():
                                               "note": "seed probe + ranked blocks + coalesced share of query/result words; ceiling = "
                                                       "tools/calib_gather.hip: 8-B probes into a 34-137 GiB table (53 on 2 GiB; 44 when whole 128-B lines are consumed)"}
 
+    if rank == 0:
+        # nominal peak next to a measured streaming figure (device-to-device copy, read + write bytes)
+        a = torch.empty(1 << 30, dtype=torch.uint8, device=dev)
+        b = torch.empty_like(a)
+        b.copy_(a)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            b.copy_(a)
+        e1.record()
+        torch.cuda.synchronize()
+        result["roofline"]["peak_measured_stream_copy"] = 10 * 2 * a.numel() / (e0.elapsed_time(e1) * 1e-3) / 1e9
+        del a, b
+
     if rank == 0 and world == 1:
         extra = {}
         if not args.no_variants:

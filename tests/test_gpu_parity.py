@@ -388,6 +388,49 @@ def test_seed_and_verify_in_the_kmer_kernel(oracle):
         ix.set_verify(-1)
 
 
+def test_per_lane_verify_of_the_two_phase_schedule(oracle):
+    """phase 1 of the two-phase schedule settles probed singletons by itself (SA read + text window per lane, queued in
+    LDS until two per lane are pending): exact counts for present / absent / near-miss k-mers, candidates too close to
+    the text's beginning, windows crossing N runs and record delimiters, and batch sizes that leave partial queues"""
+    from awry_amd import _lib
+    L_ = _lib.load_library()
+    text, st, hd = synth.make_text(300000, 0, 4711, 3, 0.03)
+    ix = gpu_index(text, 0, 8, 0, st, hd)
+    oi = oracle.OracleIndex.from_text(text, 0, 8, 0, st, hd)
+    ix.set_verify(0)
+    assert ix.verify_enabled()
+    rng = np.random.default_rng(12)
+    try:
+        L_.awry_debug_set_count_kernel(3)
+        for L, k in ((31, 10), (32, 9), (20, 10), (13, 10), (12, 10), (31, 11)):
+            i0 = L - k
+            pres = synth.sampled_queries(text, 3000, L, L)
+            near = pres.copy()  # one substitution left of the seed window: the singleton survives the probe, the text decides
+            col = rng.integers(0, max(1, i0), size=len(near))
+            near[np.arange(len(near)), col] = synth.NT[(np.searchsorted(synth.NT[:4], near[np.arange(len(near)), col]) + 1) % 4]
+            # the seed part taken from the first few text positions, a random left part: candidate with vp < L - k
+            head = np.stack([np.concatenate([synth.NT[rng.integers(0, 4, size=i0 - 1)], text[p - 1:p + k]]) for p in range(1, 12)])
+            # windows that cross N runs / delimiters: reads starting right after every non-ACGT position
+            bad = np.flatnonzero(~np.isin(text[:-L - 1], synth.NT[:4]))[:400]
+            edge = text[(bad + 1)[:, None] + np.arange(L)[None, :]]
+            edge = edge[np.isin(edge, synth.NT[:4]).all(axis=1)]
+            q2d = np.concatenate([pres, near, head, edge, synth.random_queries(2001, L, 0, L)])
+            q2d = q2d[np.isin(q2d, synth.NT).all(axis=1)]
+            q2d = q2d[rng.permutation(len(q2d))]
+            want, _ = oi.parallel_count(*synth.fixed_to_csr(q2d), 4)
+            ix.set_seed_kmer_len(k)
+            for nq in (len(q2d), 1, 63, 64, 129, 1000):
+                assert np.array_equal(ix.count_kmers_nt2(q2d[:nq], True), want[:nq]), (L, k, nq)
+            got, census = ix.count_kmers_nt2(q2d, True, tally=True)
+            assert np.array_equal(got, want) and int(census[0]) == len(q2d)
+            # the text settled (at least) the present and the near-miss k-mers, unless the window is too short to bother
+            assert (int(census[4]) >= 3000) == (i0 >= 3), (L, k, census)
+        assert "probe" in ix.count_schedule(31)
+    finally:
+        L_.awry_debug_set_count_kernel(-1)
+        ix.set_verify(-1)
+
+
 @pytest.mark.parametrize("L,verify", [(31, -1), (101, -1), (101, 2), (150, 0)])
 def test_host_locate_fast_path_equals_oracle(oracle, L, verify):
     """parallel_locate on fixed-length read batches takes the packed kernels (and seed-and-verify when enabled);

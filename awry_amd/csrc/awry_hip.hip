@@ -112,7 +112,7 @@ struct Replica {
   bool verify_kmers = false;                  // also use seed-and-verify in the k-mer (L <= 32) kernel
   std::atomic<unsigned> launch_seq{0};
   // survivor lists of the two-phase count schedule, one per stream (launches on one stream are ordered, so reuse is safe)
-  struct SurvScratch { DevBuf<uint64_t> w, range; DevBuf<uint32_t> q, count; uint64_t cap = 0; };
+  struct SurvScratch { DevBuf<uint64_t> w, range; DevBuf<uint32_t> q, count; uint64_t cap = 0, cap_q = 0; };
   std::mutex scratch_mu;
   std::map<hipStream_t, std::unique_ptr<SurvScratch>> scratch;
   int seed_k = 0;
@@ -413,6 +413,14 @@ void build_verify(awry_index* ix, Replica& r, int after_steps) {
   r.dev.verify_after = (uint32_t)after_steps;
 }
 
+// survivor lists of the two-phase schedules, one set per stream
+Replica::SurvScratch* surv_scratch(Replica& r, hipStream_t s) {
+  std::lock_guard<std::mutex> lock(r.scratch_mu);
+  auto& slot = r.scratch[s];
+  if (!slot) slot = std::make_unique<Replica::SurvScratch>();
+  return slot.get();
+}
+
 void launch_count_nt2_long(Replica& r, const uint64_t* d_words, uint64_t n, int L, uint64_t* d_counts, uint64_t* d_range_start,
                            bool use_seed, hipStream_t s) {
   require(r.dev.alphabet == NUCLEOTIDE, "packed 2-bit queries need a nucleotide index");
@@ -422,6 +430,26 @@ void launch_count_nt2_long(Replica& r, const uint64_t* d_words, uint64_t n, int 
   if (r.dev.text4 && r.dev.dense_ratio == 1) {
     const bool sd = use_seed && r.seed_k > 0 && r.seed_k <= L;
     const dim3 g(grid_for(r, n * 4, 256)), b(256);
+    const int om = count_kernel_override();
+    if (sd && L - r.seed_k >= 3 && L <= 512 && n < (1ull << 32) && (om < 0 || om == 3)) {
+      // two-phase: a per-lane pass settles the reads their seed entry (plus one SA read and one text window) decides,
+      // the quad kernel works through the rest
+      Replica::SurvScratch* sc = surv_scratch(r, s);
+      const unsigned nblk = (unsigned)r.num_cus * 8;  // both phases use this grid
+      const uint64_t per_block = ((n + (uint64_t)nblk * 256 - 1) / ((uint64_t)nblk * 256)) * 256;  // reads a block sees
+      if (sc->cap_q < per_block * nblk) {
+        HIP_CHECK(hipStreamSynchronize(s));
+        sc->q.alloc(per_block * nblk);
+        sc->cap_q = per_block * nblk;
+        sc->cap = 0;  // the k-mer path re-allocates its three lists together
+      }
+      if (!sc->count.p) sc->count.alloc(nblk);
+      const Nt2Survivors sv{nullptr, nullptr, sc->q.p, sc->count.p, per_block};
+      hipLaunchKernelGGL(count_nt2_reads_probe_kernel, dim3(nblk), b, 0, s, r.dev, d_words, n, L, d_counts, d_range_start, sv);
+      hipLaunchKernelGGL((count_nt2_reads_kernel<true, true, true>), dim3(nblk), b, 0, s, r.dev, d_words, n, L, d_counts, d_range_start, sv);
+      HIP_CHECK(hipGetLastError());
+      return;
+    }
     if (sd) hipLaunchKernelGGL((count_nt2_reads_kernel<true, true>), g, b, 0, s, r.dev, d_words, n, L, d_counts, d_range_start);
     else hipLaunchKernelGGL((count_nt2_reads_kernel<false, true>), g, b, 0, s, r.dev, d_words, n, L, d_counts, d_range_start);
     HIP_CHECK(hipGetLastError());
@@ -461,13 +489,7 @@ void launch_count_nt2(Replica& r, const uint64_t* d_words, uint64_t n, int L, ui
   }
   if (kmode == 3 && seeded && n < (1ull << 32)) {
     // two-phase: per-lane seed probes decide most queries, the quad machinery resumes the survivors
-    Replica::SurvScratch* sc;
-    {
-      std::lock_guard<std::mutex> lock(r.scratch_mu);
-      auto& slot = r.scratch[s];
-      if (!slot) slot = std::make_unique<Replica::SurvScratch>();
-      sc = slot.get();
-    }
+    Replica::SurvScratch* sc = surv_scratch(r, s);
     const unsigned nblk = (unsigned)r.num_cus * 8;                       // both phases use this grid
     const uint64_t per_block = ((n + (uint64_t)nblk * 256 - 1) / ((uint64_t)nblk * 256)) * 256;  // queries a block sees
     const uint64_t total = per_block * nblk;
@@ -475,7 +497,7 @@ void launch_count_nt2(Replica& r, const uint64_t* d_words, uint64_t n, int L, ui
       HIP_CHECK(hipStreamSynchronize(s));
       sc->w.alloc(total); sc->range.alloc(total); sc->q.alloc(total);
       if (!sc->count.p) sc->count.alloc(nblk);
-      sc->cap = total;
+      sc->cap = sc->cap_q = total;
     }
     const Nt2Survivors sv{sc->w.p, sc->range.p, sc->q.p, sc->count.p, per_block};
     const dim3 gp(nblk);
@@ -972,6 +994,11 @@ const char* awry_count_schedule(const awry_index_t* idx, int L) {
   if (!idx || idx->reps.empty()) return "";
   const Replica& r = *idx->reps[0];
   const bool seeded = r.seed_k > 0 && r.seed_k <= L;
+  if (L > 32) {  // launch_count_nt2_long
+    const int om = count_kernel_override();
+    const bool two = r.dev.text4 && r.dev.dense_ratio == 1 && seeded && L - r.seed_k >= 3 && L <= 512 && (om < 0 || om == 3);
+    return two ? "count_nt2_reads_probe_kernel+count_nt2_reads_kernel" : "count_nt2_reads_kernel";
+  }
   int m = count_kernel_mode(r.dev.bwt_len, r.seed_k, seeded);
   if (m == 3 && !seeded) m = 2;
   return names[m & 3];

@@ -513,15 +513,21 @@ __device__ __forceinline__ uint64_t spread_letters16(uint64_t x) {
 
 struct Text20 { uint32_t w[5]; };  // 5 consecutive u32 of the 4-bit text: any 32 symbols at any nibble offset
 
-// Does text[g + 32 j0' .. ) equal this lane's 32-letter query word?  Lane l of the quad compares window symbols
-// [128 c + 32 l, +32) of a window of `len` symbols starting at text position g; returns 1 on a mismatch.
-__device__ __forceinline__ uint32_t verify_part(const uint32_t* __restrict__ text4, uint64_t g, int len, int c, int l, uint64_t qword) {
-  const int j0 = 128 * c + 32 * l;
-  const int m = len - j0 < 0 ? 0 : (len - j0 > 32 ? 32 : len - j0);  // symbols this lane checks
-  if (m == 0) return 0u;
-  const uint64_t t0 = g + (uint64_t)j0;
-  const Text20 t = *reinterpret_cast<const Text20*>(text4 + (t0 >> 3));
-  const int sh = 4 * (int)(t0 & 7);
+// A window of up to 32 text symbols, fetched now and compared later (so that several can be in flight per lane).
+struct TextWin { Text20 t; int m, sh; };  // m symbols starting at nibble sh/4 of t
+__device__ __forceinline__ TextWin text_window_load(const uint32_t* __restrict__ text4, uint64_t t0, int m) {
+  TextWin w;
+  w.m = m < 0 ? 0 : (m > 32 ? 32 : m);
+  w.sh = 4 * (int)(t0 & 7);
+  if (w.m > 0) w.t = *reinterpret_cast<const Text20*>(text4 + (t0 >> 3));
+  else w.t = Text20{{0u, 0u, 0u, 0u, 0u}};
+  return w;
+}
+// 1 = the window differs from the 32 letters of qword (its first m letters)
+__device__ __forceinline__ uint32_t text_window_differs(const TextWin& w, uint64_t qword) {
+  if (w.m == 0) return 0u;
+  const Text20& t = w.t;
+  const int sh = w.sh, m = w.m;
   const uint64_t a0 = (uint64_t)t.w[0] | ((uint64_t)t.w[1] << 32), a1 = (uint64_t)t.w[2] | ((uint64_t)t.w[3] << 32), a2 = t.w[4];
   const uint64_t lo = sh ? (a0 >> sh) | (a1 << (64 - sh)) : a0;
   const uint64_t hi = sh ? (a1 >> sh) | (a2 << (64 - sh)) : a1;
@@ -529,6 +535,13 @@ __device__ __forceinline__ uint32_t verify_part(const uint32_t* __restrict__ tex
   const uint64_t mlo = m >= 16 ? ~0ull : ((1ull << (4 * m)) - 1);
   const uint64_t mhi = m <= 16 ? 0ull : (m >= 32 ? ~0ull : ((1ull << (4 * (m - 16))) - 1));
   return (((lo ^ qlo) & mlo) | ((hi ^ qhi) & mhi)) ? 1u : 0u;
+}
+
+// Does text[g + 32 j0' .. ) equal this lane's 32-letter query word?  Lane l of the quad compares window symbols
+// [128 c + 32 l, +32) of a window of `len` symbols starting at text position g; returns 1 on a mismatch.
+__device__ __forceinline__ uint32_t verify_part(const uint32_t* __restrict__ text4, uint64_t g, int len, int c, int l, uint64_t qword) {
+  const int j0 = 128 * c + 32 * l;
+  return text_window_differs(text_window_load(text4, g + (uint64_t)j0, len - j0), qword);
 }
 
 // "quad4" variant of the hot kernel: a quad owns GROUPS of 4 consecutive queries (32 contiguous bytes in and out).
@@ -1100,12 +1113,18 @@ __global__ __launch_bounds__(256) void pack_nt2_kernel(const uint8_t* __restrict
 // of text per candidate.  The rows that survive are exactly the rows whose suffixes extend to the whole query, in
 // the same relative order as the final range (the suffixes share everything after the seed part), so counts and
 // locations are unchanged; the locate pass receives the verified candidates instead of a row range (RS_* words).
-template <bool USE_SEED, bool VERIFY>
+// LIST: the quads of block b work through the reads block b of count_nt2_reads_probe_kernel left undecided
+// (sv.q / sv.count, same grid) instead of all n reads.
+template <bool USE_SEED, bool VERIFY, bool LIST = false>
 __global__ __launch_bounds__(256) void count_nt2_reads_kernel(DevIndex ix, const uint64_t* __restrict__ queries, uint64_t n, int L,
-                                                              uint64_t* __restrict__ counts, uint64_t* __restrict__ range_start) {
+                                                              uint64_t* __restrict__ counts, uint64_t* __restrict__ range_start,
+                                                              Nt2Survivors sv = Nt2Survivors{}) {
   const int l = threadIdx.x & 3;
   const uint64_t nquads = ((uint64_t)gridDim.x * blockDim.x) >> 2;
-  uint64_t q = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 2;
+  const uint64_t region = LIST ? (uint64_t)blockIdx.x * sv.cap : 0;
+  uint64_t r = threadIdx.x >> 2;  // LIST: position in the block's list
+  if (LIST) n = sv.count[blockIdx.x];
+  uint64_t q = LIST ? (r < n ? sv.q[region + r] : 0) : ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 2;
   const uint64_t* __restrict__ blocks = ix.blocks;
   const SeedEntry* __restrict__ seed = ix.seed;
   const uint32_t* __restrict__ dense = ix.dense_sa;
@@ -1114,7 +1133,7 @@ __global__ __launch_bounds__(256) void count_nt2_reads_kernel(DevIndex ix, const
   const int verify_after = (int)ix.verify_after;
   const uint32_t cA = (uint32_t)ix.prefix_sums[1], cC = (uint32_t)ix.prefix_sums[2], cG = (uint32_t)ix.prefix_sums[3],
                  cN = (uint32_t)ix.prefix_sums[4], cT = (uint32_t)ix.prefix_sums[5], cEnd = (uint32_t)ix.prefix_sums[6];
-  bool have = q < n, fresh = true;
+  bool have = LIST ? r < n : q < n, fresh = true;
   uint64_t w = 0;
   uint32_t sp = 1, ep = 0;
   int i = 0, steps_done = 0;
@@ -1193,13 +1212,134 @@ __global__ __launch_bounds__(256) void count_nt2_reads_kernel(DevIndex ix, const
           counts[q] = out_count;
           if (range_start) range_start[q] = out_rs;
         }
-        q += nquads;
-        have = q < n;
+        if (LIST) {
+          r += 64;
+          have = r < n;
+          q = have ? sv.q[region + r] : 0;
+        } else {
+          q += nquads;
+          have = q < n;
+        }
         fresh = true;
         mode = 0;
       }
     }
   }
+}
+
+// Phase 1 of the two-phase schedule for reads (seed table + dense SA + 4-bit text resident, 3 <= L - k): one read per
+// LANE.  The seed entry alone settles reads whose seed k-mer is absent or a singleton with the wrong BWT symbol; a
+// singleton with the right symbol is one candidate, settled by SA[sp] and the L - k letters of text in front of it
+// (queued in LDS so that full waves issue those loads, as in count_nt2_probe_kernel); the rest (2+ rows, saturated
+// entries) goes to block-private lists that count_nt2_reads_kernel<.., LIST> works through with the quad machinery.
+// Results are those of count_nt2_reads_kernel<true, true> (counts and RS_* range-start words).
+__global__ __launch_bounds__(256) void count_nt2_reads_probe_kernel(DevIndex ix, const uint64_t* __restrict__ queries, uint64_t n, int L,
+                                                                    uint64_t* __restrict__ counts, uint64_t* __restrict__ range_start,
+                                                                    Nt2Survivors sv) {
+  constexpr int VQ = 192;
+  __shared__ unsigned int s_count;
+  __shared__ uint32_t s_vsp[4][VQ], s_vq[4][VQ];
+  if (threadIdx.x == 0) s_count = 0;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wv_id = threadIdx.x >> 6;
+  const SeedEntry* __restrict__ seed = ix.seed;
+  const int k = ix.seed_k, i0 = L - k, W = (L + 31) / 32;
+  const int wa = i0 >> 5, wsh = 2 * (i0 & 31);            // seed window: letters i0 .. L-1
+  const int na = (i0 - 1) >> 5, nsh = 2 * ((i0 - 1) & 31);  // the letter in front of it
+  const int nchunks = (i0 + 31) >> 5;
+  const uint64_t kmask = (1ull << (2 * k)) - 1;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  const uint64_t lane_lt = (1ull << lane) - 1;
+  const uint64_t region = (uint64_t)blockIdx.x * sv.cap;
+  int vcount = 0;
+  auto settle = [&](uint64_t q, uint64_t count, uint64_t rs) {
+    counts[q] = count;
+    if (range_start) range_start[q] = rs;
+  };
+  auto drain = [&](int base, int cnt) {  // queue entries [base, base + cnt), cnt <= 128: two per lane
+    uint32_t q[2], sp[2], vp[2];
+    bool on[2];
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      const int s = base + lane + 64 * h;
+      on[h] = lane + 64 * h < cnt;
+      q[h] = on[h] ? s_vq[wv_id][s] : 0;
+      sp[h] = on[h] ? s_vsp[wv_id][s] : 0;
+      vp[h] = on[h] ? ix.dense_sa[sp[h]] : 0;
+    }
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      if (!on[h]) continue;
+      uint32_t bad = vp[h] >= (uint32_t)i0 ? 0u : 1u;  // else the suffix starts too close to the text's beginning
+      const uint64_t g = (uint64_t)vp[h] - (uint64_t)i0;
+      const uint64_t* qw = queries + (uint64_t)q[h] * W;
+      for (int c = 0; c < nchunks && !bad; c++) bad = verify_part(ix.text4, g, i0, c >> 2, c & 3, qw[c]);
+      if (!bad) settle(q[h], 1, (RS_SINGLE << RS_MODE_SHIFT) | g);
+      else settle(q[h], 0, (RS_MULTI << RS_MODE_SHIFT) | (uint64_t)sp[h] | ((uint64_t)i0 << 32));
+    }
+  };
+  constexpr int NQ = 2;  // reads in flight per lane
+  for (uint64_t wbase = (uint64_t)blockIdx.x * blockDim.x + (threadIdx.x & ~63u); wbase < n; wbase += NQ * stride) {
+    uint64_t qv[NQ], win[NQ];
+    uint32_t nc[NQ];
+    SeedEntry ev[NQ];
+#pragma unroll
+    for (int h = 0; h < NQ; h++) {
+      qv[h] = wbase + lane + (uint64_t)h * stride;
+      win[h] = 0;
+      nc[h] = 0;
+      if (qv[h] < n) {
+        const uint64_t* qw = queries + qv[h] * W;
+        win[h] = qw[wa] >> wsh;
+        if (wsh && wa + 1 < W) win[h] |= qw[wa + 1] << (64 - wsh);
+        nc[h] = (uint32_t)(qw[na] >> nsh) & 3u;
+      }
+    }
+#pragma unroll
+    for (int h = 0; h < NQ; h++) {
+      ev[h] = SeedEntry{1u, 0u};
+      if (qv[h] < n) ev[h] = seed[win[h] & kmask];
+    }
+#pragma unroll
+    for (int h = 0; h < NQ; h++) {
+      const bool valid = qv[h] < n;
+      const SeedEntry e = ev[h];
+      const uint32_t cnt = seed_cnt(e);
+      bool survivor = false, queued = false;
+      if (valid) {
+        if (cnt == 0u) settle(qv[h], 0, (RS_PLAIN << RS_MODE_SHIFT) | 1ull);
+        else if (cnt == 1u) {
+          queued = seed_sym(e) == (int)(nc[h] == 3u ? 5u : nc[h] + 1u);
+          if (!queued) settle(qv[h], 0, (RS_PLAIN << RS_MODE_SHIFT) | 1ull);  // BWT[sp] is not the next letter: absent
+        } else survivor = true;  // 2+ rows, or a saturated entry
+      }
+      const uint64_t qm = __ballot(queued);
+      if (qm) {
+        if (queued) {
+          const int s = vcount + (int)__popcll(qm & lane_lt);
+          s_vsp[wv_id][s] = e.sp;
+          s_vq[wv_id][s] = (uint32_t)qv[h];
+        }
+        vcount += (int)__popcll(qm);
+        __builtin_amdgcn_wave_barrier();
+        if (vcount >= 128) {
+          vcount -= 128;
+          drain(vcount, 128);
+          __builtin_amdgcn_wave_barrier();
+        }
+      }
+      const uint64_t sm = __ballot(survivor);
+      if (sm) {
+        unsigned int slot0 = 0;
+        if (lane == 0) slot0 = atomicAdd(&s_count, (unsigned int)__popcll(sm));
+        slot0 = __shfl(slot0, 0, 64);
+        if (survivor) sv.q[region + slot0 + (uint64_t)__popcll(sm & lane_lt)] = (uint32_t)qv[h];
+      }
+    }
+  }
+  if (vcount > 0) drain(0, vcount);
+  __syncthreads();
+  if (threadIdx.x == 0) sv.count[blockIdx.x] = s_count;
 }
 
 // ------------------------------------------------------------------------------------------------

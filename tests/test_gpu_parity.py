@@ -431,6 +431,44 @@ def test_per_lane_verify_of_the_two_phase_schedule(oracle):
         ix.set_verify(-1)
 
 
+@pytest.mark.parametrize("L", [14, 40, 101, 150, 257, 600])
+def test_two_phase_reads_schedule_matches_single_kernel_and_oracle(oracle, L):
+    """reads of any length: the per-lane probe + verify pass followed by the quad kernel on the undecided reads gives the
+    counts, locations and order of the single quad kernel and of the oracle (mostly-unique seeds, so the per-lane path
+    carries the batch); L = 600 is beyond the two-phase limit and L - k < 3 below it: both fall back by themselves"""
+    from awry_amd import _lib
+    L_ = _lib.load_library()
+    text, st, hd = synth.make_text(400000, 0, 99 + L, 2, 0.03)
+    ix = gpu_index(text, 0, 8, 0, st, hd)
+    oi = oracle.OracleIndex.from_text(text, 0, 8, 0, st, hd)
+    rng = np.random.default_rng(L)
+    pres = synth.sampled_queries(text, 3000, L, L)
+    near = pres[:1500].copy()
+    col = rng.integers(0, L, size=len(near))
+    near[np.arange(len(near)), col] = synth.NT[(np.searchsorted(synth.NT[:4], near[np.arange(len(near)), col]) + 1) % 4]
+    k = 10 if L > 14 else 12
+    head = np.stack([np.concatenate([synth.NT[rng.integers(0, 4, size=L - k - 1)], text[p - 1:p + k]]) for p in range(1, 9)])
+    first = text[np.arange(0, 6)[:, None] + np.arange(L)[None, :]]  # reads that start at text positions 0..5
+    q2d = np.concatenate([pres, near, head, first, synth.random_queries(1500, L, 0, L)])
+    q2d = q2d[np.isin(q2d, synth.NT).all(axis=1)]
+    q2d = q2d[rng.permutation(len(q2d))]
+    ooff, ogpos, opos, _ = oi.parallel_locate(*synth.fixed_to_csr(q2d), 4)
+    ix.set_verify(0)
+    ix.set_seed_kmer_len(k)
+    try:
+        for nq in (len(q2d), 1, 64, 129, 777):
+            cut = int(ooff[nq])
+            L_.awry_debug_set_count_kernel(-1)
+            two = ix.locate_reads_nt2(q2d[:nq])
+            L_.awry_debug_set_count_kernel(0)
+            one = ix.locate_reads_nt2(q2d[:nq])
+            for x, y, z in zip(two, one, (ooff[:nq + 1], ogpos[:cut], opos[:cut])):
+                assert np.array_equal(x, y) and np.array_equal(x, z), (L, nq)
+    finally:
+        L_.awry_debug_set_count_kernel(-1)
+        ix.set_verify(-1)
+
+
 @pytest.mark.parametrize("L,verify", [(31, -1), (101, -1), (101, 2), (150, 0)])
 def test_host_locate_fast_path_equals_oracle(oracle, L, verify):
     """parallel_locate on fixed-length read batches takes the packed kernels (and seed-and-verify when enabled);

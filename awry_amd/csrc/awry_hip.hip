@@ -108,6 +108,7 @@ struct Replica {
   DevBuf<unsigned long long> chunk_counters;  // ring of work-queue heads, one per in-flight count / locate launch
   DevBuf<uint32_t> text4;                     // 4-bit text for seed-and-verify (device-only accelerator)
   DevBuf<uint32_t> dense_sa;                  // SA[j * dense_ratio] as u32 (device-only accelerator for locate)
+  DevBuf<uint32_t> sa_nblock;                 // SA of the rows whose suffix starts with N (kept while locate has to walk)
   uint32_t dense_ratio = 0;                   // 0 = use the file's bit-packed samples
   bool verify_kmers = false;                  // also use seed-and-verify in the k-mer (L <= 32) kernel
   std::atomic<unsigned> launch_seq{0};
@@ -126,6 +127,7 @@ struct Replica {
       if (ev0) (void)hipEventDestroy(ev0);
       if (ev1) (void)hipEventDestroy(ev1);
       blocks.reset(); sa_words.reset(); seq_starts.reset(); seed.reset(); chunk_counters.reset(); dense_sa.reset(); text4.reset();
+      sa_nblock.reset();
     }
   }
 };
@@ -251,6 +253,7 @@ void build_seed(awry_index* ix, Replica& r, int k) {
 
 void build_dense_sa(awry_index* ix, Replica& r, int ratio);
 void build_verify(awry_index* ix, Replica& r, int after_steps);
+void refresh_nblock(awry_index* ix, Replica& r);
 
 std::unique_ptr<Replica> make_replica(awry_index* ix, int device) {
   int ndev = 0;
@@ -295,6 +298,7 @@ std::unique_ptr<Replica> make_replica(awry_index* ix, int device) {
   d.text4 = nullptr;
   d.dense_ratio = 0;
   d.verify_after = 0;
+  d.sa_nblock = nullptr;
   build_seed(ix, *r, ix->seed_k_request < 0 ? default_seed_k(h) : ix->seed_k_request);
   build_dense_sa(ix, *r, ix->dense_ratio_request);
   int vreq = ix->verify_request;
@@ -308,6 +312,7 @@ std::unique_ptr<Replica> make_replica(awry_index* ix, int device) {
   }
   if (vreq >= 0) build_verify(ix, *r, vreq);
   r->verify_kmers = ix->verify_kmers_request;
+  refresh_nblock(ix, *r);
   return r;
 }
 
@@ -366,6 +371,17 @@ void launch_locate(Replica& r, const uint64_t* d_range_start, int rs_stride, con
     hipLaunchKernelGGL(locate_tile_kernel<AMINO>, g, b, 0, s, r.dev, d_range_start, rs_stride, d_hit_off, n, total, dense, r.dense_ratio,
                        d_gpos, d_pos, ctr);
   HIP_CHECK(hipGetLastError());
+  if (r.dense_ratio == 1) return;  // every row is a sampled row: nothing was deferred
+  // the hits whose row is not sampled walk in a second pass that is not tied to tiles (locate_walk_kernel)
+  unsigned long long* wctr = next_counter(r, s);
+  const dim3 gw(grid_for(r, total, 256, 7));
+  static const bool generic_walk = getenv("AWRY_LOCATE_WALK") && !strcmp(getenv("AWRY_LOCATE_WALK"), "generic");
+  if (r.dev.alphabet == NUCLEOTIDE && !generic_walk)
+    hipLaunchKernelGGL(locate_walk_nt_lane_kernel, dim3(grid_for(r, total, 256, 8)), b, 0, s, r.dev, total, dense, r.dense_ratio, d_gpos, wctr);
+  else if (r.dev.alphabet == NUCLEOTIDE) hipLaunchKernelGGL(locate_walk_kernel<NUCLEOTIDE>, gw, b, 0, s, r.dev, total, dense, r.dense_ratio, d_gpos, d_pos, wctr);
+  else hipLaunchKernelGGL(locate_walk_kernel<AMINO>, gw, b, 0, s, r.dev, total, dense, r.dense_ratio, d_gpos, d_pos, wctr);
+  if (d_pos) hipLaunchKernelGGL(localise_walked_kernel, dim3(grid_for(r, total, 256)), b, 0, s, r.dev, total, d_gpos, d_pos);
+  HIP_CHECK(hipGetLastError());
 }
 
 // dense device SA for locate: ratio 0 = off (walk to the file's samples), r >= 1 = keep SA[j r] for every j as u32
@@ -390,6 +406,28 @@ void build_dense_sa(awry_index* ix, Replica& r, int ratio) {
   r.dense_ratio = (uint32_t)ratio;
   r.dev.dense_sa = r.dense_sa.p;
   r.dev.dense_ratio = r.dense_ratio;
+}
+
+// While locate has to walk (no ratio-1 dense SA), a nucleotide replica keeps the SA values of the BWT's N block: a walk
+// that runs into an N run stops there instead of following the run (see DevIndex::sa_nblock).  4 B per N of the text.
+void refresh_nblock(awry_index* ix, Replica& r) {
+  const HostIndex& h = ix->host;
+  const uint64_t lo = h.alphabet == NUCLEOTIDE ? h.prefix_sums[4] : 0, hi = h.alphabet == NUCLEOTIDE ? h.prefix_sums[5] : 0;
+  const bool want = h.alphabet == NUCLEOTIDE && narrow(h) && r.dense_ratio != 1 && hi - lo >= 64;
+  if (!want) {
+    r.sa_nblock.reset();
+    r.dev.sa_nblock = nullptr;
+    return;
+  }
+  if (r.sa_nblock.p) return;  // depends on the index only
+  DevBuf<uint32_t> d(hi - lo);
+  const uint64_t nsamples = (h.bwt_len + h.sa_ratio - 1) / h.sa_ratio;
+  hipLaunchKernelGGL(nblock_sa_kernel<NUCLEOTIDE>, dim3(grid_for(r, nsamples, 256, 64)), dim3(256), 0, r.stream, r.dev, nsamples,
+                     (uint32_t)lo, (uint32_t)hi, d.p);
+  HIP_CHECK(hipGetLastError());
+  HIP_CHECK(hipStreamSynchronize(r.stream));
+  r.sa_nblock = std::move(d);
+  r.dev.sa_nblock = r.sa_nblock.p;
 }
 
 // seed-and-verify for packed nucleotide reads: needs the ratio-1 dense SA and the 4-bit text, both recovered from the
@@ -1230,7 +1268,10 @@ int awry_set_locate_sa_ratio(awry_index_t* idx, int ratio) {
     require(idx != nullptr, "null index");
     require(ratio >= 0 && ratio <= 1024, "dense SA ratio must be in 0..1024");
     idx->dense_ratio_request = ratio;
-    for (size_t s = 0; s < idx->reps.size(); s++) build_dense_sa(idx, replica(idx, (int)s), ratio);
+    for (size_t s = 0; s < idx->reps.size(); s++) {
+      build_dense_sa(idx, replica(idx, (int)s), ratio);
+      refresh_nblock(idx, replica(idx, (int)s));
+    }
   });
 }
 int awry_set_verify(awry_index_t* idx, int after_steps) {
@@ -1239,7 +1280,10 @@ int awry_set_verify(awry_index_t* idx, int after_steps) {
     require(after_steps >= -1 && after_steps <= 1000, "verify threshold out of range");
     idx->verify_request = after_steps;
     if (after_steps >= 0) idx->dense_ratio_request = 1;
-    for (size_t s = 0; s < idx->reps.size(); s++) build_verify(idx, replica(idx, (int)s), after_steps);
+    for (size_t s = 0; s < idx->reps.size(); s++) {
+      build_verify(idx, replica(idx, (int)s), after_steps);
+      refresh_nblock(idx, replica(idx, (int)s));
+    }
   });
 }
 int awry_set_verify_kmers(awry_index_t* idx, int on) {

@@ -1350,11 +1350,40 @@ constexpr int LOC_QCAP = 1024;  // query (offset, start) pairs cached in LDS per
 
 // value of the suffix array at a sampled row: the file's bit-packed samples (rows r % sa_ratio == 0) or the
 // dense device array (rows r % dense_ratio == 0, u32 entries) built by densify_sa_kernel
+constexpr uint64_t LOC_WALK_FLAG = 1ull << 63;  // gpos[h] holds a BWT row that still has to walk to a sampled row
+
+// global text position -> (record, offset): largest i with seq_starts[i] <= g (the intended semantics of
+// src/sequence_index.rs:108-141, see SURVEY a-17)
+__device__ __forceinline__ void localise(const DevIndex& ix, uint64_t g, uint64_t* __restrict__ out) {
+  uint64_t a = 0, z = ix.nseq;
+  while (z - a > 1) { uint64_t mid = (a + z) >> 1; if (ix.seq_starts[mid] <= g) a = mid; else z = mid; }
+  out[0] = a;
+  out[1] = g - (ix.nseq ? ix.seq_starts[a] : 0);
+}
+
+// row -> "is it a sampled row" / sample index, without a 64-bit division per backstep (the test runs once per LF step;
+// a generic u64 modulo is ~100 instructions and made the walk ALU-bound): power-of-two ratios (the default 8) use a
+// mask and a shift, other ratios a 32-bit division while the row fits.
+__device__ __forceinline__ bool ratio_divides(uint64_t ratio, uint64_t row) {
+  if ((ratio & (ratio - 1)) == 0) return (row & (ratio - 1)) == 0;
+  if ((row >> 32) == 0 && (ratio >> 32) == 0) return (uint32_t)row % (uint32_t)ratio == 0u;
+  return row % ratio == 0;
+}
+__device__ __forceinline__ uint64_t ratio_quotient(uint64_t ratio, uint64_t row) {
+  if ((ratio & (ratio - 1)) == 0) return row >> (63 - __clzll((long long)ratio));
+  if ((row >> 32) == 0 && (ratio >> 32) == 0) return (uint32_t)row / (uint32_t)ratio;
+  return row / ratio;
+}
 __device__ __forceinline__ bool row_is_sampled(const DevIndex& ix, const uint32_t* dense, uint32_t dense_ratio, uint64_t row) {
-  return dense ? (row % dense_ratio == 0) : (row % ix.sa_ratio == 0);
+  return ratio_divides(dense ? (uint64_t)dense_ratio : ix.sa_ratio, row);
 }
 __device__ __forceinline__ uint64_t row_sample(const DevIndex& ix, const uint32_t* dense, uint32_t dense_ratio, uint64_t row) {
-  return dense ? (uint64_t)dense[row / dense_ratio] : sa_sample(ix, row / ix.sa_ratio);
+  return dense ? (uint64_t)dense[ratio_quotient(dense_ratio, row)] : sa_sample(ix, ratio_quotient(ix.sa_ratio, row));
+}
+// (sample + steps) % bwt_len of src/fm_index.rs:534; sample < bwt_len and a walk is shorter than the text
+__device__ __forceinline__ uint64_t walked_position(uint64_t sample, uint64_t steps, uint64_t bwt_len) {
+  const uint64_t g = sample + steps;
+  return g >= bwt_len ? g - bwt_len : g;
 }
 
 // dense[j] = SA[j * dense_ratio] for every j, recovered from the file's samples by CHAINS: the thread of sampled row
@@ -1431,7 +1460,7 @@ __global__ __launch_bounds__(256) void locate_tile_kernel(DevIndex ix, const uin
     }
     __syncthreads();
     bool need = true, direct = false;
-    uint64_t h = 0, row = 0, steps = 0, gd = 0;
+    uint64_t h = 0, row = 0, gd = 0;
     for (;;) {
       if (need) {
         const int t = atomicAdd(&s_cursor, 1);
@@ -1460,25 +1489,222 @@ __global__ __launch_bounds__(256) void locate_tile_kernel(DevIndex ix, const uin
         } else {
           row = rs + j;
         }
-        steps = 0;
         need = false;
       }
       if (direct || row_is_sampled(ix, dense, dense_ratio, row)) {
-        const uint64_t g = direct ? gd : (row_sample(ix, dense, dense_ratio, row) + steps) % ix.bwt_len;  // src/fm_index.rs:534
+        const uint64_t g = direct ? gd : walked_position(row_sample(ix, dense, dense_ratio, row), 0, ix.bwt_len);  // src/fm_index.rs:534, 0 steps
         gpos[h] = g;
-        if (pos) {
-          uint64_t a = 0, z = ix.nseq;  // largest i with seq_starts[i] <= g
-          while (z - a > 1) { uint64_t mid = (a + z) >> 1; if (ix.seq_starts[mid] <= g) a = mid; else z = mid; }
-          pos[2 * h] = a;
-          pos[2 * h + 1] = g - (ix.nseq ? ix.seq_starts[a] : 0);
+        if (pos) localise(ix, g, pos + 2 * h);
+      } else {
+        gpos[h] = row | LOC_WALK_FLAG;  // a walk kernel finishes this hit,
+        if (pos) pos[2 * h] = ~0ull;    // localise_walked_kernel its record / offset
+      }
+      need = true;
+    }
+    __syncthreads();
+  }
+}
+
+// Second pass of locate: the hits whose row is not a sampled one walk the LF-mapping to the next sample
+// (src/fm_index.rs:521-540).  Walk lengths are geometric (mean ratio - 1, tail ~6x that), so hits are not tied to
+// blocks or tiles: every wave draws batches of LOC_WALK_BATCH consecutive hit indices from one device-wide counter and
+// its lanes take the next index of the batch whenever their walk ends -- no lane idles behind a long walk except at the
+// very end of the launch.  (Inside the tile kernel the same walks ran at ~40 % lane utilisation.)
+constexpr int LOC_WALK_BATCH = 512;
+template <int A>
+__global__ __launch_bounds__(256) void locate_walk_kernel(DevIndex ix, uint64_t total, const uint32_t* __restrict__ dense, uint32_t dense_ratio,
+                                                          uint64_t* __restrict__ gpos, uint64_t* __restrict__ pos,
+                                                          unsigned long long* __restrict__ batch_counter) {
+  const int lane = threadIdx.x & 63;
+  const uint64_t lane_lt = (1ull << lane) - 1;
+  uint64_t cur = 0, end = 0;  // wave-uniform: the unassigned rest of this wave's batch
+  bool exhausted = false;     // wave-uniform: the counter has run past the last hit
+  bool need = true;
+  uint64_t h = 0, row = 0, steps = 0;
+  for (;;) {
+    const uint64_t nm = __ballot(need);
+    if (nm) {
+      if (cur == end && !exhausted) {
+        unsigned long long base = 0;
+        if (lane == 0) base = atomicAdd(batch_counter, (unsigned long long)LOC_WALK_BATCH);
+        base = __shfl(base, 0, 64);
+        cur = base < total ? base : total;
+        end = base + LOC_WALK_BATCH < total ? base + LOC_WALK_BATCH : total;
+        exhausted = cur == end;
+      }
+      if (exhausted && nm == ~0ull) break;  // nothing left to hand out and every lane is idle
+      if (need) {
+        const uint64_t idx = cur + (uint64_t)__popcll(nm & lane_lt);
+        if (idx < end) {
+          const uint64_t v = gpos[idx];
+          if (v & LOC_WALK_FLAG) { h = idx; row = v & ~LOC_WALK_FLAG; steps = 0; need = false; }
         }
+      }
+      const uint64_t adv = cur + (uint64_t)__popcll(nm);
+      cur = adv < end ? adv : end;
+    }
+    if (!need) {
+      if (row_is_sampled(ix, dense, dense_ratio, row)) {
+        gpos[h] = walked_position(row_sample(ix, dense, dense_ratio, row), steps, ix.bwt_len);  // src/fm_index.rs:534
         need = true;
       } else {
         row = backstep_scalar<A>(ix, row);
         steps++;
       }
     }
-    __syncthreads();
+  }
+}
+
+// Third pass of locate, after a walk kernel: record / offset of the hits the tile pass deferred (pos[2h] == ~0).  Kept
+// out of the walk kernels on purpose: the binary search over the record starts is a chain of dependent loads, and
+// inside a state machine every wave iteration in which any quad emits would wait for all of it.
+__global__ __launch_bounds__(256) void localise_walked_kernel(DevIndex ix, uint64_t total, const uint64_t* __restrict__ gpos,
+                                                              uint64_t* __restrict__ pos) {
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t h = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; h < total; h += stride)
+    if (pos[2 * h] == ~0ull) localise(ix, gpos[h], pos + 2 * h);
+}
+
+// SA values of the N block of the BWT (DevIndex::sa_nblock), by the chains of densify_sa_kernel: the thread of
+// sampled row s walks LF until the next sampled row and records the rows of the window [lo, hi) it passes.
+template <int A>
+__global__ __launch_bounds__(256) void nblock_sa_kernel(DevIndex ix, uint64_t nsamples, uint32_t lo, uint32_t hi, uint32_t* __restrict__ out) {
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  const uint32_t fr = ix.sa_ratio;
+  for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < nsamples; j += stride) {
+    uint32_t row = (uint32_t)(j * fr);
+    uint32_t v = (uint32_t)sa_sample(ix, j);
+    for (;;) {
+      if (row - lo < hi - lo) out[row - lo] = v;
+      row = (uint32_t)backstep_scalar<A>(ix, row);
+      if (row % fr == 0u) break;
+      v--;
+    }
+  }
+}
+
+// Nucleotide walk kernel.  One hit per LANE, whole block per step: the lane fetches the 128-B block of its row with
+// eight 16-B loads issued back to back (one line, one memory latency), then takes the BWT symbol and the rank from
+// registers; the generic locate_walk_kernel above spends two dependent round trips per step (symbol, then rank) on
+// ~14 separate 8-B loads.  Rows are u64, so it also serves indexes >= 2^32.
+//
+// Each lane is a three-state machine -- FETCH the next hit's row, WALK one backstep, EMIT at a sampled row -- and the
+// lanes of a wave are in different states.  Written naively (load and use inside each branch) an iteration costs the
+// SUM of the memory latencies of the branches present in the wave; here every iteration first issues the one load
+// group each lane needs, under its state's predicate, and only then consumes the results.
+//
+// Measured on MI355X (GRCh38-scale, 5 M hits, ratio 8; locate = tile pass + walk + localise): walking inside the tile
+// kernel 1.91 ms; this kernel 1.50 ms; a quad-cooperative variant (4 lanes per hit, 2 loads per lane, DPP reductions)
+// 1.65 ms -- it was instruction-bound (~230 instructions per 16 steps), this one is bound by the texture path's
+// per-lane line lookups (8 per step).
+__global__ __launch_bounds__(256) void locate_walk_nt_lane_kernel(DevIndex ix, uint64_t total, const uint32_t* __restrict__ dense,
+                                                                  uint32_t dense_ratio, uint64_t* __restrict__ gpos,
+                                                                  unsigned long long* __restrict__ batch_counter) {
+  const int lane = threadIdx.x & 63;
+  const uint64_t lane_lt = (1ull << lane) - 1;
+  const uint64_t* __restrict__ blocks = ix.blocks;
+  const uint64_t cA = ix.prefix_sums[1], cC = ix.prefix_sums[2], cG = ix.prefix_sums[3], cN = ix.prefix_sums[4], cT = ix.prefix_sums[5];
+  const uint32_t* __restrict__ nblock = ix.sa_nblock;
+  const uint64_t nspan = nblock ? cT - cN : 0ull;  // rows [cN, cN + nspan) resolve through nblock
+  const uint64_t sa_bits = ix.sa_bits, bwt_len = ix.bwt_len, sentinel = ix.sentinel_row;
+  const uint64_t ratio = dense ? (uint64_t)dense_ratio : (uint64_t)ix.sa_ratio;
+  auto stops = [&](uint64_t row) { return ratio_divides(ratio, row) || row - cN < nspan; };
+  uint64_t cur = 0, end = 0;  // wave-uniform: the unassigned rest of this wave's batch
+  bool exhausted = false;     // wave-uniform
+  enum { IDLE = 0, FETCH = 1, WALK = 2, EMIT = 3 };
+  int state = IDLE;
+  uint64_t h = 0, row = 0, steps = 0;
+  for (;;) {
+    const uint64_t nm = __ballot(state == IDLE);
+    if (nm) {
+      if (cur == end && !exhausted) {
+        unsigned long long base = 0;
+        if (lane == 0) base = atomicAdd(batch_counter, (unsigned long long)LOC_WALK_BATCH);
+        base = __shfl(base, 0, 64);
+        cur = base < total ? base : total;
+        end = base + LOC_WALK_BATCH < total ? base + LOC_WALK_BATCH : total;
+        exhausted = cur == end;
+      }
+      if (exhausted && nm == ~0ull) break;
+      if (state == IDLE) {
+        const uint64_t idx = cur + (uint64_t)__popcll(nm & lane_lt);
+        if (idx < end) { h = idx; state = FETCH; }
+      }
+      const uint64_t adv = cur + (uint64_t)__popcll(nm);
+      cur = adv < end ? adv : end;
+    }
+    // ---- issue
+    uint64_t v = 0, s0 = 0, s1 = 0, ss = 0;
+    ulonglong2 B[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) B[j] = ulonglong2{0, 0};
+    if (state == FETCH) v = gpos[h];
+    if (state == WALK) {
+      const ulonglong2* p = reinterpret_cast<const ulonglong2*>(blocks + (row >> 8) * NT_BLOCK_WORDS);
+#pragma unroll
+      for (int j = 0; j < 8; j++) B[j] = p[j];
+    }
+    if (state == EMIT) {
+      if (row - cN < nspan) {
+        s0 = nblock[row - cN];
+      } else if (dense) {
+        s0 = dense[ratio_quotient(ratio, row)];
+      } else {  // src/compressed_suffix_array.rs:76-106
+        const uint64_t off = ratio_quotient(ratio, row) * sa_bits;
+        ss = off & 63;
+        s0 = ix.sa_words[off >> 6];
+        s1 = ix.sa_words[(off >> 6) + 1];  // the buffer has one word of slack
+      }
+    }
+    asm volatile("" : "+v"(v), "+v"(s0), "+v"(s1), "+v"(B[0].x), "+v"(B[0].y), "+v"(B[1].x), "+v"(B[1].y), "+v"(B[2].x), "+v"(B[2].y),
+                 "+v"(B[3].x), "+v"(B[3].y), "+v"(B[4].x), "+v"(B[4].y), "+v"(B[5].x), "+v"(B[5].y), "+v"(B[6].x), "+v"(B[6].y),
+                 "+v"(B[7].x), "+v"(B[7].y));
+    // ---- consume
+    if (state == FETCH) {
+      if (v & LOC_WALK_FLAG) { row = v & ~LOC_WALK_FLAG; steps = 0; state = stops(row) ? EMIT : WALK; }
+      else state = IDLE;  // the tile pass already finished this hit
+    } else if (state == EMIT) {
+      uint64_t sample = s0;
+      if (!(row - cN < nspan) && !dense) {
+        sample = s0 >> ss;
+        if (ss + sa_bits > 64) sample |= s1 << (64 - ss);
+        if (sa_bits < 64) sample &= (1ull << sa_bits) - 1;
+      }
+      gpos[h] = walked_position(sample, steps, bwt_len);  // src/fm_index.rs:534
+      state = IDLE;
+    } else if (state == WALK) {  // backstep, src/fm_index.rs:585-593; B[j] = {plane0[j], plane1[j]}, B[4 + j] = {plane2[j], milestone[j]}
+      const uint64_t b = row >> 8;
+      const int w = (int)((row >> 6) & 3), bit = (int)(row & 63);
+      const uint64_t q0 = w == 0 ? B[0].x : (w == 1 ? B[1].x : (w == 2 ? B[2].x : B[3].x));
+      const uint64_t q1 = w == 0 ? B[0].y : (w == 1 ? B[1].y : (w == 2 ? B[2].y : B[3].y));
+      const uint64_t q2 = w == 0 ? B[4].x : (w == 1 ? B[5].x : (w == 2 ? B[6].x : B[7].x));
+      const uint32_t code = (uint32_t)((q0 >> bit) & 1ull) | ((uint32_t)((q1 >> bit) & 1ull) << 1) | ((uint32_t)((q2 >> bit) & 1ull) << 2);
+      steps++;
+      if (code == 4u) {
+        row = 0;  // '$': the walk continues from row 0
+      } else {
+        const int t = code == 6u ? 0 : (code == 5u ? 1 : (code == 3u ? 2 : (code == 1u ? 3 : -1)));  // A C G T, else N
+        const uint32_t pc = t >= 0 ? code : 2u;  // as nt_index_of_code: anything else ranks as N (010)
+        const uint64_t x0 = (pc & 1u) ? 0ull : ~0ull, x1 = (pc & 2u) ? 0ull : ~0ull, x2 = (pc & 4u) ? 0ull : ~0ull;
+        const uint64_t last = ~0ull >> (63 - bit);
+        uint32_t cnt = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const uint64_t m = j < w ? ~0ull : (j == w ? last : 0ull);
+          cnt += (uint32_t)__popcll((B[j].x ^ x0) & (B[j].y ^ x1) & (B[4 + j].x ^ x2) & m);
+        }
+        uint64_t ms, c0;
+        if (t >= 0) {
+          ms = t == 0 ? B[4].y : (t == 1 ? B[5].y : (t == 2 ? B[6].y : B[7].y));
+          c0 = t == 0 ? cA : (t == 1 ? cC : (t == 2 ? cG : cT));
+        } else {  // N: rows before the block that are neither A, C, G, T nor the single '$'
+          ms = 256ull * b - (B[4].y + B[5].y + B[6].y + B[7].y) - (sentinel < 256ull * b ? 1ull : 0ull);
+          c0 = cN;
+        }
+        row = c0 + ms + cnt - 1;
+      }
+      if (stops(row)) state = EMIT;
+    }
   }
 }
 

@@ -92,6 +92,9 @@ struct DevIndex {
   const uint32_t* text4;      // the text as 4-bit codes (A0 C1 G2 T3, 8 = anything else), 8 symbols per u32, LSB first
   uint32_t dense_ratio;
   uint32_t verify_after;      // seed-and-verify: switch from LF steps to text comparison after this many steps
+  const uint32_t* sa_nblock;  // SA of every row whose suffix starts with N (rows [C[N], C[T])), or nullptr: ends locate
+                              //   walks that run into an N run, where LF moves by a constant stride and row sampling can
+                              //   leave a walk without a sampled row for the length of the run
 };
 
 // encoding of a query's "range start" word handed from the count pass to the locate pass

@@ -469,6 +469,41 @@ def test_two_phase_reads_schedule_matches_single_kernel_and_oracle(oracle, L):
         ix.set_verify(-1)
 
 
+def test_locate_walks_next_to_long_n_runs(oracle):
+    """row sampling + N runs: inside a run LF moves by a constant stride (the number of runs at least that long), so a
+    walk that enters a run at a row of the wrong residue meets no sampled row until the run ends -- tens of thousands of
+    dependent steps for a read that starts right after a gap.  The replica keeps the SA of the BWT's N block for that
+    case (DevIndex::sa_nblock); locations stay those of the oracle, which simply walks"""
+    rng = np.random.default_rng(5)
+    parts, cuts = [], []
+    for run in (30000, 30000, 12000, 12000):  # two pairs of equal-length runs: strides 4 and 2 inside them
+        parts.append(synth.NT[rng.integers(0, 4, size=20000)])
+        parts.append(np.full(run, ord("N"), dtype=np.uint8))
+        cuts.append(sum(len(x) for x in parts))
+    parts.append(synth.NT[rng.integers(0, 4, size=20000)])
+    text = np.concatenate(parts + [np.frombuffer(b"$", np.uint8)])
+    ix = gpu_index(text, 0, 8, 0, [0], ["gappy"])
+    oi = oracle.OracleIndex.from_text(text, 0, 8, 0, [0], ["gappy"])
+    L = 28
+    starts = np.concatenate([np.arange(c, c + 12) for c in cuts] + [rng.integers(0, 19000, size=300)])
+    reads = text[starts[:, None] + np.arange(L)[None, :]]
+    reads = reads[np.isin(reads, synth.NT).all(axis=1)]
+    qb, qo = synth.fixed_to_csr(reads)
+    ooff, ogpos, opos, tl = oi.parallel_locate(qb, qo, 4)
+    assert tl["backsteps"] > 20000  # the reference-style walk really is long here
+    ix.set_verify(-1)
+    for ratio in (0, 3):  # the file's samples (ratio 8), a dense device SA that is not 1
+        ix.set_locate_sa_ratio(ratio)
+        off, g, p = ix.parallel_locate_csr(qb, qo)
+        assert np.array_equal(off, ooff) and np.array_equal(g, ogpos) and np.array_equal(p, opos), ratio
+        got = ix.locate_reads_nt2(reads)
+        assert all(np.array_equal(x, y) for x, y in zip(got, (ooff, ogpos, opos))), ratio
+    # queries made of N walk inside the runs themselves
+    qn = [b"N" * 5, b"NNNNNNNNNNNNNNNNNNNN" + bytes(text[cuts[0]:cuts[0] + 6])]
+    for q in qn:
+        assert np.array_equal(ix.locate_string_raw(q)[0], oi.locate_string(q)[0])  # same order too: ascending BWT row
+
+
 @pytest.mark.parametrize("L,verify", [(31, -1), (101, -1), (101, 2), (150, 0)])
 def test_host_locate_fast_path_equals_oracle(oracle, L, verify):
     """parallel_locate on fixed-length read batches takes the packed kernels (and seed-and-verify when enabled);

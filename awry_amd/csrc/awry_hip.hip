@@ -96,11 +96,51 @@ struct PackedLane {
   }
 };
 
+template <class T>
+struct PinBuf {  // pinned host staging, grows on demand
+  T* p = nullptr;
+  size_t cap = 0;
+  PinBuf() = default;
+  PinBuf(const PinBuf&) = delete;
+  PinBuf& operator=(const PinBuf&) = delete;
+  ~PinBuf() { if (p) (void)hipHostFree(p); }
+  void ensure(size_t n) {
+    if (n <= cap) return;
+    if (p) (void)hipHostFree(p);
+    p = nullptr;
+    cap = 0;
+    const size_t c = n + n / 4 + 1024;
+    hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&p), c * sizeof(T), hipHostMallocDefault);
+    if (e != hipSuccess) { p = nullptr; throw HipError(std::string("hipHostMalloc failed: ") + hipGetErrorString(e)); }
+    cap = c;
+  }
+};
+
+// one pipeline lane of the packed host locate path (locate_shard_packed); persists in the replica
+struct LocateLane {
+  hipEvent_t counted = nullptr, located = nullptr;
+  DevBuf<uint8_t> ascii;
+  DevBuf<uint64_t> words, rstart, counts, hit_off, scratch, gpos, pos;
+  DevBuf<unsigned long long> bad;
+  PinBuf<uint64_t> h_counts, h_gpos, h_meta;  // h_meta: [0] total hits of the chunk, [1] reads with bytes outside ACGT
+  PinBuf<awry_pos_t> h_pos;
+  uint64_t lo = 0, hi = 0, total = 0;
+  int stage = 0;                               // 0 idle, 1 count queued, 2 locate queued
+  std::vector<uint64_t> fb_gpos, fb_counts;    // a chunk redone by the generic kernel keeps its results here
+  std::vector<awry_pos_t> fb_pos;
+  bool fallback = false;
+  ~LocateLane() {
+    if (counted) (void)hipEventDestroy(counted);
+    if (located) (void)hipEventDestroy(located);
+  }
+};
+
 struct Replica {
   int device = -1;
   hipStream_t stream = nullptr;
   hipStream_t lane_stream[2] = {nullptr, nullptr};  // the two pipeline lanes of the packed host path
   PackedLane lanes[2];
+  LocateLane loc_lanes[2];
   std::mutex lane_mu;  // one packed host call at a time per replica
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   DevBuf<uint64_t> blocks, sa_words, seq_starts;
@@ -779,67 +819,210 @@ void count_shard_generic(Replica& r, const uint8_t* qbytes, const uint64_t* qoff
   }
 }
 
-struct LocateResult {  // per shard, rebased by the caller
-  std::vector<uint64_t> hit_counts, gpos;
-  std::vector<awry_pos_t> pos;
+template <class T>
+struct MBuf {  // malloc'ed, geometrically growing array whose storage can be handed to the caller (awry_free_buffer = free)
+  T* p = nullptr;
+  size_t cap = 0;
+  MBuf() = default;
+  MBuf(const MBuf&) = delete;
+  MBuf& operator=(const MBuf&) = delete;
+  MBuf(MBuf&& o) noexcept : p(o.p), cap(o.cap) { o.p = nullptr; o.cap = 0; }
+  ~MBuf() { free(p); }
+  void grow(size_t need) {
+    if (need <= cap) return;
+    const size_t c = std::max(need, cap + cap / 2 + 4096);
+    T* q = static_cast<T*>(realloc(p, c * sizeof(T)));
+    if (!q) throw std::bad_alloc();
+    p = q;
+    cap = c;
+  }
+  T* release() { T* q = p; p = nullptr; cap = 0; return q; }
 };
+
+struct LocateResult {  // per shard, in query order
+  uint64_t* off = nullptr;  // the shard's slice of the batch's offset array: off[i + 1] - off[i] = hits of query i; the
+                            //   shard writes off[1..n] relative to its own first hit, the caller rebases
+  uint64_t nq = 0, filled = 0, running = 0;
+  MBuf<uint64_t> gpos;
+  MBuf<awry_pos_t> pos;
+  size_t total = 0;
+  void add_counts(const uint64_t* counts, uint64_t n) {  // next n queries of the shard
+    for (uint64_t i = 0; i < n; i++) { running += counts[i]; off[filled + i + 1] = running; }
+    filled += n;
+  }
+  void append(const uint64_t* g, const awry_pos_t* p, size_t n, bool want_gpos) {
+    if (!n) return;
+    if (total + n > pos.cap && filled && filled < nq) {  // size the arrays for the whole shard from the hit rate so far
+      const size_t est = (size_t)((double)(total + n) / (double)filled * (double)nq * 1.05) + 4096;
+      pos.grow(est);
+      if (want_gpos) gpos.grow(est);
+    }
+    pos.grow(total + n);
+    memcpy(pos.p + total, p, n * sizeof(awry_pos_t));
+    if (want_gpos) {
+      gpos.grow(total + n);
+      memcpy(gpos.p + total, g, n * 8);
+    }
+    total += n;
+  }
+};
+
+// generic kernels, synchronous: any alphabet, ragged lengths, ambiguity codes
+void locate_chunk_generic(Replica& r, const uint8_t* qbytes, const uint64_t* qoff, Shard c, uint64_t* counts_out,
+                          std::vector<uint64_t>& gpos, std::vector<awry_pos_t>& pos) {
+  ChunkBuffers cb;
+  const uint64_t n = c.hi - c.lo;
+  run_count_chunk(r, cb, qbytes, qoff, c, true);
+  DevBuf<uint64_t> hit_off(n + 1), scratch(scan_tiles(n) + 1);
+  launch_scan(r, cb.counts.p, n, hit_off.p, scratch.p, r.stream);
+  uint64_t total = 0;
+  HIP_CHECK(hipMemcpyAsync(&total, hit_off.p + n, 8, hipMemcpyDeviceToHost, r.stream));
+  HIP_CHECK(hipMemcpyAsync(counts_out, cb.counts.p, n * 8, hipMemcpyDeviceToHost, r.stream));
+  HIP_CHECK(hipStreamSynchronize(r.stream));
+  check_status(cb, c.lo);
+  gpos.resize(total);
+  pos.resize(total);
+  if (total == 0) return;
+  DevBuf<uint64_t> d_gpos(total), d_pos(2 * total);
+  launch_locate(r, cb.ranges.p, 2, hit_off.p, n, total, d_gpos.p, d_pos.p, r.stream);
+  HIP_CHECK(hipMemcpyAsync(pos.data(), d_pos.p, total * 16, hipMemcpyDeviceToHost, r.stream));
+  HIP_CHECK(hipMemcpyAsync(gpos.data(), d_gpos.p, total * 8, hipMemcpyDeviceToHost, r.stream));
+  HIP_CHECK(hipStreamSynchronize(r.stream));
+}
+
+void locate_shard_generic(Replica& r, const uint8_t* qbytes, const uint64_t* qoff, Shard sh, bool want_gpos, LocateResult& out) {
+  std::vector<uint64_t> g, counts;
+  std::vector<awry_pos_t> p;
+  for (Shard c : chunk_queries(qoff, sh.lo, sh.hi)) {
+    counts.resize(c.hi - c.lo);
+    locate_chunk_generic(r, qbytes, qoff, c, counts.data(), g, p);
+    out.add_counts(counts.data(), c.hi - c.lo);
+    out.append(g.data(), p.data(), p.size(), want_gpos);
+  }
+}
+
+// Fast path of parallel_locate: nucleotide index, every read the same length L.  Chunks of reads flow through the
+// replica's two stream lanes in three stages -- (1) H2D ASCII, pack, packed count with range starts, scan, D2H counts;
+// (2) once the host knows the chunk's hit total: locate kernels, D2H of the positions into pinned staging; (3) copy
+// into the result arrays -- so that one chunk's transfers and host copies overlap the other chunk's kernels.  A chunk
+// that holds bytes outside ACGT is redone by the generic kernels; results never depend on the path.
+void locate_shard_packed(Replica& r, const uint8_t* qbytes, const uint64_t* qoff, Shard sh, uint64_t L, bool want_gpos, LocateResult& out) {
+  const uint64_t CH = std::max<uint64_t>(1u << 16, std::min<uint64_t>(1u << 20, (128ull << 20) / L));  // reads per chunk
+  const uint64_t W = (L + 31) / 32;
+  static const bool trace = getenv("AWRY_TRACE_HOST") != nullptr;
+  const auto t0 = std::chrono::steady_clock::now();
+  std::lock_guard<std::mutex> lane_lock(r.lane_mu);
+  HostPin pin_in(qbytes + qoff[sh.lo], (sh.hi - sh.lo) * L);
+  LocateLane* lanes = r.loc_lanes;
+  struct Drain {  // every exit leaves the lanes idle before the input is unpinned
+    Replica& r;
+    ~Drain() {
+      for (int li = 0; li < 2; li++) {
+        if (r.loc_lanes[li].stage) (void)hipStreamSynchronize(r.lane_stream[li]);
+        r.loc_lanes[li].stage = 0;
+      }
+    }
+  } drain{r};
+  for (int li = 0; li < 2; li++) {
+    LocateLane& ln = lanes[li];
+    if (!ln.counted) HIP_CHECK(hipEventCreateWithFlags(&ln.counted, hipEventDisableTiming));
+    if (!ln.located) HIP_CHECK(hipEventCreateWithFlags(&ln.located, hipEventDisableTiming));
+    const uint64_t cap = std::min<uint64_t>(CH, sh.hi - sh.lo);
+    if (ln.ascii.n < cap * L + 16) ln.ascii.alloc(cap * L + 16);
+    if (ln.words.n < cap * W) ln.words.alloc(cap * W);
+    if (ln.rstart.n < cap) ln.rstart.alloc(cap);
+    if (ln.counts.n < cap) ln.counts.alloc(cap);
+    if (ln.hit_off.n < cap + 1) ln.hit_off.alloc(cap + 1);
+    if (ln.scratch.n < scan_tiles(cap) + 1) ln.scratch.alloc(scan_tiles(cap) + 1);
+    if (!ln.bad.p) ln.bad.alloc(1);
+    ln.h_counts.ensure(cap);
+    ln.h_meta.ensure(2);
+    ln.stage = 0;
+  }
+  auto stage1 = [&](int li, uint64_t lo, uint64_t hi) {  // count
+    LocateLane& ln = lanes[li];
+    hipStream_t s = r.lane_stream[li];
+    const uint64_t n = hi - lo;
+    ln.lo = lo;
+    ln.hi = hi;
+    ln.fallback = false;
+    HIP_CHECK(hipMemcpyAsync(ln.ascii.p, qbytes + qoff[lo], n * L, hipMemcpyHostToDevice, s));
+    HIP_CHECK(hipMemsetAsync(ln.bad.p, 0, 8, s));
+    hipLaunchKernelGGL(pack_nt2_kernel, dim3(grid_for(r, n, 256)), dim3(256), 0, s, ln.ascii.p, n, (int)L, ln.words.p, ln.bad.p);
+    HIP_CHECK(hipGetLastError());
+    launch_count_nt2_long(r, ln.words.p, n, (int)L, ln.counts.p, ln.rstart.p, true, s);
+    launch_scan(r, ln.counts.p, n, ln.hit_off.p, ln.scratch.p, s);
+    HIP_CHECK(hipMemcpyAsync(ln.h_meta.p, ln.hit_off.p + n, 8, hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipMemcpyAsync(ln.h_meta.p + 1, ln.bad.p, 8, hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipMemcpyAsync(ln.h_counts.p, ln.counts.p, n * 8, hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipEventRecord(ln.counted, s));
+    ln.stage = 1;
+  };
+  auto stage2 = [&](int li) {  // locate, once the chunk's hit total is known
+    LocateLane& ln = lanes[li];
+    if (ln.stage != 1) return;
+    hipStream_t s = r.lane_stream[li];
+    const uint64_t n = ln.hi - ln.lo;
+    HIP_CHECK(hipEventSynchronize(ln.counted));
+    if (ln.h_meta.p[1]) {  // bytes outside ACGT: the generic kernels redo this chunk (and raise INVALID_QUERY where due)
+      ln.fb_counts.resize(n);
+      locate_chunk_generic(r, qbytes, qoff, Shard{ln.lo, ln.hi}, ln.fb_counts.data(), ln.fb_gpos, ln.fb_pos);
+      out.add_counts(ln.fb_counts.data(), n);
+      ln.fallback = true;
+      ln.total = ln.fb_pos.size();
+      ln.stage = 2;
+      return;
+    }
+    out.add_counts(ln.h_counts.p, n);  // stage 2 runs in chunk order
+    ln.total = ln.h_meta.p[0];
+    if (ln.total) {
+      if (ln.gpos.n < ln.total) ln.gpos.alloc(ln.total + ln.total / 4);
+      if (ln.pos.n < 2 * ln.total) ln.pos.alloc(2 * (ln.total + ln.total / 4));
+      ln.h_pos.ensure(ln.total);
+      if (want_gpos) ln.h_gpos.ensure(ln.total);
+      launch_locate(r, ln.rstart.p, 1, ln.hit_off.p, n, ln.total, ln.gpos.p, ln.pos.p, s);
+      HIP_CHECK(hipMemcpyAsync(ln.h_pos.p, ln.pos.p, ln.total * 16, hipMemcpyDeviceToHost, s));
+      if (want_gpos) HIP_CHECK(hipMemcpyAsync(ln.h_gpos.p, ln.gpos.p, ln.total * 8, hipMemcpyDeviceToHost, s));
+    }
+    HIP_CHECK(hipEventRecord(ln.located, s));
+    ln.stage = 2;
+  };
+  auto stage3 = [&](int li) {  // results into the output arrays, in chunk order
+    LocateLane& ln = lanes[li];
+    if (ln.stage != 2) return;
+    if (ln.fallback) {
+      out.append(ln.fb_gpos.data(), ln.fb_pos.data(), ln.fb_pos.size(), want_gpos);
+    } else {
+      HIP_CHECK(hipEventSynchronize(ln.located));
+      out.append(ln.h_gpos.p, ln.h_pos.p, ln.total, want_gpos);
+    }
+    ln.stage = 0;
+  };
+  uint64_t i = 0;
+  for (uint64_t lo = sh.lo; lo < sh.hi; lo += CH, i++) {
+    const int li = (int)(i & 1);
+    stage3(li);                                   // chunk i - 2
+    stage1(li, lo, std::min(sh.hi, lo + CH));     // chunk i
+    stage2(li ^ 1);                               // chunk i - 1
+  }
+  const int last = (int)((i + 1) & 1);            // lane of chunk i - 1
+  stage2(last);
+  stage3(last ^ 1);
+  stage3(last);
+  if (trace)
+    fprintf(stderr, "[awry] packed locate shard: %llu reads, %zu hits, %.2f ms\n", (unsigned long long)(sh.hi - sh.lo), out.total,
+            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+}
 
 void locate_shard(Replica& r, const uint8_t* qbytes, const uint64_t* qoff, Shard sh, bool want_gpos, LocateResult& out) {
   HIP_CHECK(hipSetDevice(r.device));
-  ChunkBuffers cb;
-  DevBuf<uint64_t> hit_off, scratch, d_gpos, d_pos;
-  out.hit_counts.resize(sh.hi - sh.lo);
-  DevBuf<uint64_t> words, rstart;
-  DevBuf<unsigned long long> bad;
+  out.nq = sh.hi - sh.lo;
   static const bool no_fast = getenv("AWRY_HOST_PATH") && !strcmp(getenv("AWRY_HOST_PATH"), "generic");
-  for (Shard c : chunk_queries(qoff, sh.lo, sh.hi)) {
-    const uint64_t n = c.hi - c.lo;
-    // fixed-length ACGT reads take the packed quad kernel (seed table, seed-and-verify when enabled); a chunk holding
-    // any other byte is redone by the generic kernel, so the result never depends on the path taken
-    uint64_t L = 0;
-    bool packed = !no_fast && r.dev.alphabet == NUCLEOTIDE && r.dev.bwt_len < (1ull << 32) - 512 && shard_fixed_length(qoff, c, L);
-    if (packed) {
-      const uint64_t W = (L + 31) / 32, nbytes = n * L;
-      if (cb.q.n < nbytes + 16) cb.q.alloc(nbytes + 16);
-      if (words.n < n * W) words.alloc(n * W);
-      if (rstart.n < n) rstart.alloc(n);
-      if (cb.counts.n < n) cb.counts.alloc(n);
-      if (!bad.p) bad.alloc(1);
-      HIP_CHECK(hipMemcpyAsync(cb.q.p, qbytes + qoff[c.lo], nbytes, hipMemcpyHostToDevice, r.stream));
-      HIP_CHECK(hipMemsetAsync(bad.p, 0, 8, r.stream));
-      hipLaunchKernelGGL(pack_nt2_kernel, dim3(grid_for(r, n, 256)), dim3(256), 0, r.stream, cb.q.p, n, (int)L, words.p, bad.p);
-      HIP_CHECK(hipGetLastError());
-      launch_count_nt2_long(r, words.p, n, (int)L, cb.counts.p, rstart.p, true, r.stream);
-      unsigned long long h_bad = 0;
-      HIP_CHECK(hipMemcpyAsync(&h_bad, bad.p, 8, hipMemcpyDeviceToHost, r.stream));
-      HIP_CHECK(hipStreamSynchronize(r.stream));
-      packed = h_bad == 0;
-      cb.h_status.clear();
-    }
-    if (!packed) run_count_chunk(r, cb, qbytes, qoff, c, true);
-    if (hit_off.n < n + 1) hit_off.alloc(n + 1);
-    const uint64_t sb = scan_tiles(n) + 1;
-    if (scratch.n < sb) scratch.alloc(sb);
-    launch_scan(r, cb.counts.p, n, hit_off.p, scratch.p, r.stream);
-    uint64_t total = 0;
-    HIP_CHECK(hipMemcpyAsync(&total, hit_off.p + n, 8, hipMemcpyDeviceToHost, r.stream));
-    HIP_CHECK(hipMemcpyAsync(out.hit_counts.data() + (c.lo - sh.lo), cb.counts.p, n * 8, hipMemcpyDeviceToHost, r.stream));
-    HIP_CHECK(hipStreamSynchronize(r.stream));
-    check_status(cb, c.lo);
-    if (total == 0) continue;
-    if (d_gpos.n < total) d_gpos.alloc(total);
-    if (d_pos.n < 2 * total) d_pos.alloc(2 * total);
-    if (packed) launch_locate(r, rstart.p, 1, hit_off.p, n, total, d_gpos.p, d_pos.p, r.stream);
-    else launch_locate(r, cb.ranges.p, 2, hit_off.p, n, total, d_gpos.p, d_pos.p, r.stream);
-    const size_t at = out.pos.size();
-    out.pos.resize(at + total);
-    HIP_CHECK(hipMemcpyAsync(out.pos.data() + at, d_pos.p, total * 16, hipMemcpyDeviceToHost, r.stream));
-    if (want_gpos) {
-      out.gpos.resize(at + total);
-      HIP_CHECK(hipMemcpyAsync(out.gpos.data() + at, d_gpos.p, total * 8, hipMemcpyDeviceToHost, r.stream));
-    }
-    HIP_CHECK(hipStreamSynchronize(r.stream));
-  }
+  uint64_t L = 0;
+  if (!no_fast && r.dev.alphabet == NUCLEOTIDE && r.dev.bwt_len < (1ull << 32) - 512 && shard_fixed_length(qoff, sh, L))
+    locate_shard_packed(r, qbytes, qoff, sh, L, want_gpos, out);
+  else
+    locate_shard_generic(r, qbytes, qoff, sh, want_gpos, out);
 }
 
 // run fn(replica, shard, slot) on every replica concurrently; rethrow the first failure
@@ -1065,23 +1248,35 @@ int awry_locate_batch(awry_index_t* idx, const uint8_t* qbytes, const uint64_t* 
     require(idx && qoff && hit_off_out && hits_out, "null argument");
     require(qbytes || qoff[n] == qoff[0], "null query bytes");
     std::vector<LocateResult> res(std::max<size_t>(1, idx->reps.size()));
+    std::unique_ptr<uint64_t, decltype(&free)> off(malloc_array<uint64_t>(n + 1), &free);
+    off.get()[0] = 0;
+    {
+      auto shards = shard_queries(n, res.size());  // the same cut for_each_replica makes
+      for (size_t g = 0; g < res.size(); g++) res[g].off = off.get() + shards[g].lo;
+    }
     for_each_replica(idx, n, [&](Replica& r, Shard sh, int g) { locate_shard(r, qbytes, qoff, sh, global_pos_out != nullptr, res[g]); });
     uint64_t total = 0;
-    for (auto& x : res) total += x.pos.size();
-    std::unique_ptr<uint64_t, decltype(&free)> off(malloc_array<uint64_t>(n + 1), &free);
-    std::unique_ptr<awry_pos_t, decltype(&free)> hits(malloc_array<awry_pos_t>(total), &free);
-    std::unique_ptr<uint64_t, decltype(&free)> gp(global_pos_out ? malloc_array<uint64_t>(total) : nullptr, &free);
-    uint64_t qi = 0, at = 0;
-    off.get()[0] = 0;
-    for (auto& x : res) {  // shards are contiguous in query order, so concatenation keeps input order
-      for (uint64_t c : x.hit_counts) { off.get()[qi + 1] = off.get()[qi] + c; qi++; }
-      if (!x.pos.empty()) memcpy(hits.get() + at, x.pos.data(), x.pos.size() * sizeof(awry_pos_t));
-      if (gp && !x.gpos.empty()) memcpy(gp.get() + at, x.gpos.data(), x.gpos.size() * 8);
-      at += x.pos.size();
+    for (size_t g = 0; g < res.size(); g++) {  // shards are contiguous in query order: rebase every shard after the first
+      if (g && total)
+        for (uint64_t i = 1; i <= res[g].nq; i++) res[g].off[i] += total;
+      total += res[g].total;
+    }
+    if (res.size() == 1 && res[0].pos.p && (!global_pos_out || res[0].gpos.p)) {  // one replica: its arrays are the result
+      *hits_out = res[0].pos.release();
+      if (global_pos_out) *global_pos_out = res[0].gpos.release();
+    } else {
+      std::unique_ptr<awry_pos_t, decltype(&free)> hits(malloc_array<awry_pos_t>(total), &free);
+      std::unique_ptr<uint64_t, decltype(&free)> gp(global_pos_out ? malloc_array<uint64_t>(total) : nullptr, &free);
+      uint64_t at = 0;
+      for (auto& x : res) {
+        if (x.total) memcpy(hits.get() + at, x.pos.p, x.total * sizeof(awry_pos_t));
+        if (gp && x.total) memcpy(gp.get() + at, x.gpos.p, x.total * 8);
+        at += x.total;
+      }
+      *hits_out = hits.release();
+      if (global_pos_out) *global_pos_out = gp.release();
     }
     *hit_off_out = off.release();
-    *hits_out = hits.release();
-    if (global_pos_out) *global_pos_out = gp.release();
   });
 }
 

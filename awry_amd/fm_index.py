@@ -91,6 +91,30 @@ def pack_queries(queries: Iterable):
 _u64p = C.POINTER(C.c_uint64)
 
 
+class _Owned:
+    """a malloc'ed result buffer of the C ABI, exposed to numpy without a copy and released (awry_free_buffer) with
+    the last array that views it"""
+
+    def __init__(self, lib, addr, nbytes):
+        self._lib, self._addr = lib, addr
+        self.__array_interface__ = {"data": (addr, False), "shape": (nbytes,), "typestr": "|u1", "version": 3}
+
+    def __del__(self):
+        try:
+            self._lib.awry_free_buffer(C.c_void_p(self._addr))
+        except Exception:
+            pass
+
+
+def _adopt(lib, ptr, count, dtype):
+    addr = C.cast(ptr, C.c_void_p).value
+    if not count or not addr:
+        if addr:
+            lib.awry_free_buffer(C.c_void_p(addr))
+        return np.zeros(0, dtype)
+    return np.asarray(_Owned(lib, addr, count * np.dtype(dtype).itemsize)).view(dtype)
+
+
 def read_query_file(path):
     """FASTA / FASTQ file -> (uint8 bytes, uint64 offsets[n+1]): one query per record (query ingestion)"""
     L = _lib.load_library()
@@ -298,12 +322,10 @@ class FmIndex:
         n = len(qo) - 1
         off, hits, gp = _u64p(), C.POINTER(_lib.Pos)(), _u64p()
         _check(self._L.awry_locate_batch(self._h, qb.ctypes.data, qo.ctypes.data_as(_u64p), n, C.byref(off), C.byref(hits), C.byref(gp)))
-        offs = np.ctypeslib.as_array(off, shape=(n + 1,)).copy()
+        offs = _adopt(self._L, off, n + 1, np.uint64)
         tot = int(offs[-1])
-        g = np.ctypeslib.as_array(gp, shape=(tot,)).copy() if tot else np.zeros(0, np.uint64)
-        p = np.ctypeslib.as_array(C.cast(hits, _u64p), shape=(2 * tot,)).copy().reshape(-1, 2) if tot else np.zeros((0, 2), np.uint64)
-        for x in (off, hits, gp):
-            self._L.awry_free_buffer(x)
+        g = _adopt(self._L, gp, tot, np.uint64)
+        p = _adopt(self._L, hits, 2 * tot, np.uint64).reshape(-1, 2)
         return offs, g, p
 
     def parallel_locate(self, queries: Iterable) -> List[List[LocalizedSequencePosition]]:

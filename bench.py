@@ -296,9 +296,9 @@ def main():
     except (OSError, ValueError):
         pass
     # the ceiling that actually binds this access pattern: random 128-B line requests (profiles/r01_gather_calibration.txt)
-    lines = probes + blocks + nq * (8.0 + 8.0) / 128.0
+    lines = probes + blocks + vsa + vtxt + nq * (8.0 + 8.0) / 128.0
     result["roofline"]["random_line_rate"] = {"achieved_Glines_s": lines / (kernel_ms * 1e-3) / 1e9, "measured_ceiling_Glines_s": 48.0,
-                                              "note": "seed probe + ranked blocks + coalesced share of query/result words; ceiling = "
+                                              "note": "seed probe + ranked blocks + verify SA reads and text windows + coalesced share of query/result words; ceiling = "
                                                       "tools/calib_gather.hip: 8-B probes into a 34-137 GiB table (53 on 2 GiB; 44 when whole 128-B lines are consumed)"}
 
     if rank == 0:
@@ -336,7 +336,9 @@ def main():
             p2, s2, b2 = [int(x) / 5 for x in tally.cpu().tolist()[:3]]
             ab = 104.0 * b2 + nq * 16.0
             extra["unseeded"] = {"queries_per_s": nq / (ms * 1e-3), "kernel_ms": ms, "achieved_GBs": ab / (ms * 1e-3) / 1e9,
-                                 "frac": ab / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "steps_per_query": s2 / nq, "block_reads_per_query": b2 / nq}
+                                 "frac": ab / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "steps_per_query": s2 / nq, "block_reads_per_query": b2 / nq,
+                                 "note": "algorithmic bytes (104 B per ranked block) can exceed the HBM peak here: the blocks of the first ~10 steps "
+                                         "of every query are shared by all queries and come from L2 / Infinity Cache"}
             # queries drawn from the text: present => all L - k steps execute
             ns = min(nq, 2_000_000)
             present = synth.sampled_queries(text, ns, L, 77)
@@ -358,11 +360,13 @@ def main():
             tally.zero_()
             ix.dev_count_nt2_tally(d_words.data_ptr(), ns, L, counts.data_ptr(), tally.data_ptr(), True, stream, 0)
             torch.cuda.synchronize()
-            p3, s3, b3 = [int(x) for x in tally.cpu().tolist()[:3]]
-            ab = 16.0 * p3 + 104.0 * b3 + ns * 16.0
+            p3, s3, b3, v3, t3 = [int(x) for x in tally.cpu().tolist()[:5]]
+            ab = 16.0 * p3 + 104.0 * b3 + ns * 16.0 + 8.0 * v3 + 8.0 * t3
             extra["present_queries"] = {"queries": ns, "queries_per_s": ns / (ms * 1e-3), "kernel_ms": ms,
                                         "achieved_GBs": ab / (ms * 1e-3) / 1e9, "frac": ab / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                        "steps_per_query": s3 / ns}
+                                        "steps_per_query": s3 / ns, "verify_sa_reads_per_query": v3 / ns,
+                                        "verify_text_windows_per_query": t3 / ns,
+                                        "random_lines_per_s": (p3 + b3 + v3 + t3) / (ms * 1e-3)}
             # the same present k-mers by LF steps only (seed-and-verify accelerators dropped): the contrast to the default
             want_present = counts[:ns].clone()
             had_verify = ix.verify_enabled()

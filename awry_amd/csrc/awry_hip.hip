@@ -1396,16 +1396,7 @@ int awry_block_reference_layout(const awry_index_t* idx, uint64_t block, uint64_
 int awry_read_query_file(const char* path, uint8_t** qbytes_out, uint64_t** qoff_out, uint64_t* n_out) {
   return guarded([&] {
     require(path && qbytes_out && qoff_out && n_out, "null argument");
-    std::vector<uint8_t> bytes;
-    std::vector<uint64_t> off;
-    read_query_file(path, bytes, off);
-    std::unique_ptr<uint8_t, decltype(&free)> b(malloc_array<uint8_t>(bytes.size()), &free);
-    std::unique_ptr<uint64_t, decltype(&free)> o(malloc_array<uint64_t>(off.size()), &free);
-    if (!bytes.empty()) memcpy(b.get(), bytes.data(), bytes.size());
-    memcpy(o.get(), off.data(), off.size() * 8);
-    *n_out = off.size() - 1;
-    *qbytes_out = b.release();
-    *qoff_out = o.release();
+    read_query_file(path, qbytes_out, qoff_out, n_out);
   });
 }
 

@@ -8,6 +8,11 @@
 #include <stdexcept>
 #include <thread>
 
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
 #include "alphabet.h"
 #include "sais.hpp"
 
@@ -41,63 +46,267 @@ static std::string first_token(const char* p, size_t n) {
   return std::string(p, k);
 }
 
-// FASTA (multi-line records) or FASTQ (4-line records) -> fn(header token, sequence bytes as written)
-template <class F>
-static void for_each_record(const std::string& path, F&& fn) {
-  std::ifstream in(path, std::ios::binary);
-  if (!in) throw std::runtime_error("cannot open sequence file: " + path);
-  std::string line, header, seq;
-  bool first = true, fastq = false, open_rec = false;
-  int state = 0;  // fastq: 0 header, 1 sequence, 2 '+', 3 quality
-  auto flush = [&] { if (open_rec) fn(header, seq); open_rec = false; seq.clear(); };
-  while (std::getline(in, line)) {
-    while (!line.empty() && (line.back() == '\r' || line.back() == '\n')) line.pop_back();
-    if (first && !line.empty()) { fastq = line[0] == '@'; first = false; }
-    bool is_header = fastq ? state == 0 : (!line.empty() && line[0] == '>');
-    if (is_header) {
-      if (line.empty()) continue;
-      flush();
-      header = first_token(line.data() + 1, line.size() - 1);
-      open_rec = true;
-      if (fastq) state = 1;
-      continue;
+namespace {
+
+// A sequence file mapped into memory and cut into chunks that start at record boundaries, so that threads can
+// parse them independently.  FASTA: multi-line records, a line starting with '>' is a header.  FASTQ: strict
+// 4-line records.  Sequence bytes are kept as written, minus whitespace.
+struct MappedFile {
+  const char* p = nullptr;
+  size_t n = 0;
+  int fd = -1;
+  bool mapped = false;
+  std::vector<char> owned;
+  explicit MappedFile(const std::string& path) {
+    fd = open(path.c_str(), O_RDONLY);
+    if (fd < 0) throw std::runtime_error("cannot open sequence file: " + path);
+    struct stat st;
+    if (fstat(fd, &st) != 0) { close(fd); throw std::runtime_error("cannot stat sequence file: " + path); }
+    n = (size_t)st.st_size;
+    if (n == 0) return;
+    void* m = mmap(nullptr, n, PROT_READ, MAP_PRIVATE, fd, 0);
+    if (m != MAP_FAILED) {
+      p = static_cast<const char*>(m);
+      mapped = true;
+      (void)madvise(m, n, MADV_SEQUENTIAL);
+    } else {  // not mappable (pipe, odd file system): read it
+      owned.resize(n);
+      size_t got = 0;
+      while (got < n) {
+        ssize_t r = read(fd, owned.data() + got, n - got);
+        if (r <= 0) break;
+        got += (size_t)r;
+      }
+      n = got;
+      p = owned.data();
     }
-    if (fastq && state == 2) { state = 3; continue; }
-    if (fastq && state == 3) { state = 0; continue; }
-    if (!open_rec && !line.empty()) { header.clear(); open_rec = true; }  // sequence data before any header
-    for (char c : line)
-      if (!isspace((unsigned char)c)) seq.push_back(c);
-    if (fastq) state = 2;
   }
-  flush();
+  ~MappedFile() {
+    if (mapped) munmap(const_cast<char*>(p), n);
+    if (fd >= 0) close(fd);
+  }
+  MappedFile(const MappedFile&) = delete;
+  MappedFile& operator=(const MappedFile&) = delete;
+};
+
+inline const char* line_end(const char* q, const char* end) {
+  const char* e = static_cast<const char*>(memchr(q, '\n', (size_t)(end - q)));
+  return e ? e : end;
 }
+
+struct SeqScanner {
+  const char* p;
+  const char* end;
+  bool fastq = false;
+  std::vector<const char*> cuts;  // chunk t = [cuts[t], cuts[t + 1])
+
+  SeqScanner(const MappedFile& f, unsigned threads) : p(f.p), end(f.p + f.n) {
+    const char* q = p;
+    while (q < end && (*q == '\n' || *q == '\r')) q++;  // format = first character of the first non-empty line
+    fastq = q < end && *q == '@';
+    cuts.push_back(p);
+    const size_t n = f.n;
+    for (unsigned t = 1; t < threads; t++) {
+      const char* c = record_start_after(p + n / threads * t);
+      if (c > cuts.back() && c < end) cuts.push_back(c);
+    }
+    cuts.push_back(end);
+  }
+
+  // first record start at or after q (end if none)
+  const char* record_start_after(const char* q) const {
+    if (q <= p) return p;
+    q = line_end(q - 1, end);  // q - 1: a cut that already sits on a line start stays there
+    while (q < end) {
+      const char* ls = q + 1;  // start of the next line
+      if (ls >= end) return end;
+      if (!fastq) {
+        if (*ls == '>') return ls;
+      } else if (*ls == '@') {  // a header, unless it is a quality line: then line + 2 is a sequence, not a '+' line
+        const char* l1 = line_end(ls, end);                         // end of the candidate header line
+        const char* l2 = l1 < end ? line_end(l1 + 1, end) : end;    // end of the line after it
+        if (l2 < end && l2 + 1 < end && l2[1] == '+') return ls;
+      }
+      q = line_end(ls, end);
+    }
+    return end;
+  }
+
+  // fn(header, header_len, emit) per record of chunk t, in file order; emit(ptr, len) delivers sequence bytes piecewise
+  template <class Rec>
+  void for_each_in_chunk(size_t t, Rec&& rec) const {
+    const char* q = cuts[t];
+    const char* e = cuts[t + 1];
+    if (fastq) {
+      int state = 0;  // 0 header, 1 sequence, 2 '+', 3 quality
+      const char* hdr = nullptr;
+      size_t hlen = 0;
+      while (q < e) {
+        const char* le = line_end(q, e);
+        const char* te = le;
+        while (te > q && (te[-1] == '\r' || te[-1] == '\n')) te--;
+        if (state == 0) {
+          if (te > q) { hdr = q + 1; hlen = (size_t)(te - q - 1); state = 1; }
+        } else if (state == 1) {
+          rec.record(hdr, hlen, q, (size_t)(te - q), true);
+          state = 2;
+        } else if (state == 2) {
+          state = 3;
+        } else {
+          state = 0;
+        }
+        q = le < e ? le + 1 : e;
+      }
+      if (state == 1) rec.record(hdr, hlen, q, 0, true);  // header without a sequence line
+    } else {
+      bool open_rec = false;
+      while (q < e) {
+        const char* le = line_end(q, e);
+        const char* te = le;
+        while (te > q && (te[-1] == '\r' || te[-1] == '\n')) te--;
+        if (te > q && *q == '>') {
+          rec.record(q + 1, (size_t)(te - q - 1), nullptr, 0, false);
+          open_rec = true;
+        } else if (te > q) {
+          if (!open_rec) { rec.record(q, 0, nullptr, 0, false); open_rec = true; }  // sequence data before any header
+          rec.more(q, (size_t)(te - q));
+        }
+        q = le < e ? le + 1 : e;
+      }
+    }
+  }
+};
+
+// C-locale isspace: ' ', \t \n \v \f \r
+inline bool is_space(unsigned char c) { return c == ' ' || (c >= 9 && c <= 13); }
+// lines are trimmed at the right already; inner whitespace is rare, so look for it with a branch-free scan first
+inline bool has_space(const char* q, size_t n) {
+  unsigned any = 0;
+  for (size_t i = 0; i < n; i++) any |= (unsigned)is_space((unsigned char)q[i]);
+  return any != 0;
+}
+inline size_t count_nonspace(const char* q, size_t n) {
+  if (!has_space(q, n)) return n;
+  size_t k = 0;
+  for (size_t i = 0; i < n; i++) k += !is_space((unsigned char)q[i]);
+  return k;
+}
+inline uint8_t* copy_nonspace(uint8_t* dst, const char* q, size_t n, bool upper) {
+  if (!has_space(q, n)) {
+    if (!upper) { memcpy(dst, q, n); return dst + n; }
+    for (size_t i = 0; i < n; i++) {  // ASCII upper-casing, vectorisable
+      const unsigned char c = (unsigned char)q[i];
+      dst[i] = (uint8_t)(c - ((c >= 'a' && c <= 'z') ? 32 : 0));
+    }
+    return dst + n;
+  }
+  for (size_t i = 0; i < n; i++) {
+    const unsigned char c = (unsigned char)q[i];
+    if (!is_space(c)) *dst++ = upper ? (uint8_t)toupper(c) : c;
+  }
+  return dst;
+}
+
+struct ChunkTally {  // pass 1
+  uint64_t records = 0, bytes = 0;
+  void record(const char*, size_t, const char* seq, size_t n, bool) { records++; bytes += count_nonspace(seq, n); }
+  void more(const char* seq, size_t n) { bytes += count_nonspace(seq, n); }
+};
+
+unsigned reader_threads(size_t bytes) {
+  const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+  return (unsigned)std::max<size_t>(1, std::min<size_t>(std::min(hw, 16u), bytes >> 22));  // >= 4 MiB per thread
+}
+
+template <class F>
+void run_chunks(size_t nchunks, F&& fn) {
+  if (nchunks == 1) { fn(0); return; }
+  std::vector<std::thread> pool;
+  std::vector<std::exception_ptr> errs(nchunks);
+  for (size_t t = 0; t < nchunks; t++)
+    pool.emplace_back([&, t] { try { fn(t); } catch (...) { errs[t] = std::current_exception(); } });
+  for (auto& th : pool) th.join();
+  for (auto& e : errs) if (e) std::rethrow_exception(e);
+}
+
+}  // namespace
 
 // Text model of src/fm_index.rs:148-153,182,220-223: records joined by one delimiter byte ('N' / 'X'),
 // one trailing '$'.  The reader itself (libsufr::util::read_sequence_file) is not in the reference tree;
 // letters are upper-cased (ignore_softmask: true, src/fm_index.rs:161) and the header is the first
 // whitespace-delimited token.  Parity is pinned only for upper-case canonical letters.
+// Two parallel passes over the mapped file: tally records / bytes per chunk, then fill.
 SequenceFile read_sequence_file(const std::string& path, int alphabet) {
+  MappedFile f(path);
+  SeqScanner sc(f, reader_threads(f.n));
+  const size_t nc = sc.cuts.size() - 1;
+  std::vector<ChunkTally> tally(nc);
+  run_chunks(nc, [&](size_t t) { sc.for_each_in_chunk(t, tally[t]); });
+  std::vector<uint64_t> rec0(nc + 1, 0), byte0(nc + 1, 0);
+  for (size_t t = 0; t < nc; t++) { rec0[t + 1] = rec0[t] + tally[t].records; byte0[t + 1] = byte0[t] + tally[t].bytes; }
+  const uint64_t nrec = rec0[nc];
+  if (nrec == 0) throw std::runtime_error("no sequence records in " + path);
   SequenceFile sf;
+  sf.text.resize(byte0[nc] + (nrec - 1) + 1);  // + delimiters + '$'
+  sf.starts.resize(nrec);
+  sf.headers.resize(nrec);
   const uint8_t delim = alphabet == NUCLEOTIDE ? 'N' : 'X';
-  for_each_record(path, [&](const std::string& header, const std::string& seq) {
-    if (!sf.starts.empty()) sf.text.push_back(delim);
-    sf.starts.push_back(sf.text.size());
-    sf.headers.push_back(header);
-    for (char c : seq) sf.text.push_back((uint8_t)toupper((unsigned char)c));
+  struct Fill {
+    SequenceFile& sf;
+    uint64_t rec, at;  // next record index, next text position
+    uint8_t delim;
+    void record(const char* h, size_t hn, const char* seq, size_t n, bool) {
+      if (rec) sf.text[at++] = delim;
+      sf.starts[rec] = at;
+      sf.headers[rec] = first_token(h, hn);
+      rec++;
+      at = (uint64_t)(copy_nonspace(sf.text.data() + at, seq, n, true) - sf.text.data());
+    }
+    void more(const char* seq, size_t n) { at = (uint64_t)(copy_nonspace(sf.text.data() + at, seq, n, true) - sf.text.data()); }
+  };
+  run_chunks(nc, [&](size_t t) {
+    // record r of the file starts at text position bytes_before + r (one delimiter per earlier record)
+    Fill fill{sf, rec0[t], byte0[t] + (rec0[t] ? rec0[t] - 1 : 0), delim};
+    sc.for_each_in_chunk(t, fill);
   });
-  if (sf.starts.empty()) throw std::runtime_error("no sequence records in " + path);
-  sf.text.push_back('$');
+  sf.text.back() = '$';
   return sf;
 }
 
-// query ingestion: every record of a FASTA/FASTQ file becomes one query of a CSR batch
-void read_query_file(const std::string& path, std::vector<uint8_t>& bytes, std::vector<uint64_t>& offsets) {
-  bytes.clear();
-  offsets.assign(1, 0);
-  for_each_record(path, [&](const std::string&, const std::string& seq) {
-    bytes.insert(bytes.end(), seq.begin(), seq.end());
-    offsets.push_back(bytes.size());
-  });
+// query ingestion: every record of a FASTA/FASTQ file becomes one query of a CSR batch.
+// The arrays are malloc'ed (the C ABI hands them to the caller, awry_free_buffer = free).
+void read_query_file(const std::string& path, uint8_t** bytes_out, uint64_t** offsets_out, uint64_t* n_out) {
+  MappedFile f(path);
+  SeqScanner sc(f, reader_threads(f.n));
+  const size_t nc = sc.cuts.size() - 1;
+  std::vector<ChunkTally> tally(nc);
+  run_chunks(nc, [&](size_t t) { sc.for_each_in_chunk(t, tally[t]); });
+  std::vector<uint64_t> rec0(nc + 1, 0), byte0(nc + 1, 0);
+  for (size_t t = 0; t < nc; t++) { rec0[t + 1] = rec0[t] + tally[t].records; byte0[t + 1] = byte0[t] + tally[t].bytes; }
+  const uint64_t nrec = rec0[nc];
+  uint8_t* bytes = static_cast<uint8_t*>(malloc(std::max<uint64_t>(1, byte0[nc])));
+  uint64_t* offsets = static_cast<uint64_t*>(malloc((nrec + 1) * 8));
+  if (!bytes || !offsets) { free(bytes); free(offsets); throw std::bad_alloc(); }
+  struct Fill {
+    uint8_t* bytes;
+    uint64_t* offsets;
+    uint64_t rec, at;
+    void record(const char*, size_t, const char* seq, size_t n, bool) {
+      offsets[rec++] = at;
+      at = (uint64_t)(copy_nonspace(bytes + at, seq, n, false) - bytes);
+    }
+    void more(const char* seq, size_t n) { at = (uint64_t)(copy_nonspace(bytes + at, seq, n, false) - bytes); }
+  };
+  try {
+    run_chunks(nc, [&](size_t t) {
+      Fill fill{bytes, offsets, rec0[t], byte0[t]};
+      sc.for_each_in_chunk(t, fill);
+    });
+  } catch (...) { free(bytes); free(offsets); throw; }
+  offsets[nrec] = byte0[nc];
+  *bytes_out = bytes;
+  *offsets_out = offsets;
+  *n_out = nrec;
 }
 
 // ------------------------------------------------------------------ packing

@@ -41,8 +41,8 @@ uint64_t ref_kmer_table_entries(int alphabet, unsigned kmer_len);
 // FASTA / FASTQ -> text model of src/fm_index.rs:148-153 (throws std::runtime_error)
 SequenceFile read_sequence_file(const std::string& path, int alphabet);
 
-// FASTA / FASTQ -> one query per record, CSR (bytes, offsets[n+1])
-void read_query_file(const std::string& path, std::vector<uint8_t>& bytes, std::vector<uint64_t>& offsets);
+// FASTA / FASTQ -> one query per record, CSR (bytes, offsets[n+1]); malloc'ed arrays owned by the caller
+void read_query_file(const std::string& path, uint8_t** bytes_out, uint64_t** offsets_out, uint64_t* n_out);
 
 // The single pass over the suffix array of src/fm_index.rs:203-240, emitting the device layout.
 // `sa` may be u32 or u64 values (sa32 != nullptr selects u32).

@@ -120,11 +120,8 @@ def read_query_file(path):
     L = _lib.load_library()
     b, o, n = C.POINTER(C.c_uint8)(), _u64p(), C.c_uint64()
     _check(L.awry_read_query_file(os.fsencode(path), C.byref(b), C.byref(o), C.byref(n)))
-    off = np.ctypeslib.as_array(o, shape=(int(n.value) + 1,)).copy()
-    tot = int(off[-1])
-    qb = np.ctypeslib.as_array(b, shape=(tot,)).copy() if tot else np.zeros(0, np.uint8)
-    L.awry_free_buffer(b)
-    L.awry_free_buffer(o)
+    off = _adopt(L, o, int(n.value) + 1, np.uint64)
+    qb = _adopt(L, b, int(off[-1]), np.uint8)
     return qb, off
 
 

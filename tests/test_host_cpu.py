@@ -161,3 +161,58 @@ def test_query_file_ingestion(tmp_path):
     with pytest.raises(AwryError) as e:
         read_query_file(str(tmp_path / "missing.fq"))
     assert e.value.code == ERR_IO
+
+
+def test_query_file_ingestion_parallel_chunks(tmp_path):
+    """files of more than a few MiB are cut at record boundaries and parsed by several threads: same CSR batch as a
+    line-by-line parse, with quality lines that start with '@' or '+', CRLF line ends, wrapped FASTA and empty records"""
+    from awry_amd.fm_index import read_query_file
+    rng = np.random.default_rng(3)
+    nt = np.frombuffer(b"ACGTNacgt", dtype=np.uint8)
+    seqs, fq = [], []
+    for i in range(60000):
+        L = int(rng.integers(0, 300)) if i % 97 else 0
+        sq = bytes(nt[rng.integers(0, len(nt), size=L)])
+        ql = bytes(rng.integers(33, 74, size=L).astype(np.uint8))
+        if i % 5 == 0 and L:
+            ql = b"@" + ql[1:]
+        if i % 7 == 0 and L:
+            ql = b"+" + ql[1:]
+        eol = b"\r\n" if i % 11 == 0 else b"\n"
+        fq.append(b"@read%d some description" % i + eol + sq + eol + (b"+read%d" % i if i % 3 else b"+") + eol + ql + eol)
+        seqs.append(sq)
+    path = tmp_path / "big.fq"
+    path.write_bytes(b"".join(fq))
+    assert path.stat().st_size > (8 << 20)
+    qb, qo = read_query_file(str(path))
+    assert len(qo) == len(seqs) + 1 and np.array_equal(np.diff(qo), [len(x) for x in seqs])
+    assert bytes(qb) == b"".join(seqs)
+    fa = []
+    for i, sq in enumerate(seqs):
+        w = 60 if i % 2 else 71
+        fa.append(b">s%d x\n" % i + b"".join(sq[j:j + w] + (b"\r\n" if i % 13 == 0 else b"\n") for j in range(0, len(sq), w)) + (b"\n" if i % 17 == 0 else b""))
+    path = tmp_path / "big.fa"
+    path.write_bytes(b"".join(fa))
+    assert path.stat().st_size > (8 << 20)
+    qb, qo = read_query_file(str(path))
+    assert np.array_equal(np.diff(qo), [len(x) for x in seqs]) and bytes(qb) == b"".join(seqs)
+
+
+def test_sequence_file_reader_parallel_chunks(tmp_path, oracle):
+    """FmIndex::new on a multi-record FASTA big enough for the chunked reader: same index as from the in-memory text"""
+    rng = np.random.default_rng(4)
+    recs = [synth.NT[rng.integers(0, 4, size=int(rng.integers(1000, 400000)))] for _ in range(60)]
+    path = tmp_path / "multi.fa"
+    with open(path, "wb") as f:
+        for i, r in enumerate(recs):
+            f.write(b">chr%d description %d\n" % (i, i))
+            low = bytes(r).lower() if i % 4 == 0 else bytes(r)
+            f.write(b"\n".join(low[j:j + 80] for j in range(0, len(low), 80)) + b"\n")
+    assert path.stat().st_size > (8 << 20)
+    ix = FmIndex.new(FmBuildArgs(str(path), suffix_array_compression_ratio=8, lookup_table_kmer_len=4))
+    text = np.concatenate([np.concatenate([r, np.frombuffer(b"N", np.uint8)]) for r in recs])[:-1]
+    text = np.concatenate([text, np.frombuffer(b"$", np.uint8)])
+    starts = np.concatenate([[0], np.cumsum([len(r) + 1 for r in recs])[:-1]])
+    want = FmIndex.from_text(text, 0, 8, 4, [int(x) for x in starts], ["chr%d" % i for i in range(len(recs))], build_device=awry_amd.fm_index.BUILD_HOST)
+    assert ix.bwt_len() == want.bwt_len() and np.array_equal(ix.device_block_words(), want.device_block_words())
+    assert ix.sequences() == want.sequences() and np.array_equal(ix.sa_words(), want.sa_words())

@@ -85,7 +85,8 @@ struct PackedLane {
   hipStream_t s = nullptr;  // owned by the replica
   hipEvent_t done = nullptr;
   DevBuf<uint8_t> ascii;
-  DevBuf<uint64_t> words, counts;
+  DevBuf<uint64_t> words, counts, off;  // off / lens: batches of unequal lengths
+  DevBuf<uint32_t> lens;
   DevBuf<unsigned long long> bad;
   unsigned long long* h_bad = nullptr;  // pinned
   uint64_t chunk_lo = 0, chunk_hi = 0;
@@ -120,7 +121,8 @@ struct PinBuf {  // pinned host staging, grows on demand
 struct LocateLane {
   hipEvent_t counted = nullptr, located = nullptr;
   DevBuf<uint8_t> ascii;
-  DevBuf<uint64_t> words, rstart, counts, hit_off, scratch, gpos, pos;
+  DevBuf<uint64_t> words, rstart, counts, hit_off, scratch, gpos, pos, off;
+  DevBuf<uint32_t> lens;
   DevBuf<unsigned long long> bad;
   PinBuf<uint64_t> h_counts, h_gpos, h_meta;  // h_meta: [0] total hits of the chunk, [1] reads with bytes outside ACGT
   PinBuf<awry_pos_t> h_pos;
@@ -358,6 +360,17 @@ std::unique_ptr<Replica> make_replica(awry_index* ix, int device) {
 
 // ---- kernel launch helpers (all asynchronous on `s`) ------------------------------------------------
 
+// ASCII -> packed 2-bit words.  d_off == nullptr: n queries of L bytes each; else query q = bytes [d_off[q] - base, d_off[q+1] - base)
+// of d_ascii (total_bytes in all), W words per query (stride), lengths to d_lens.
+void launch_pack_nt2(Replica& r, const uint8_t* d_ascii, const uint64_t* d_off, uint64_t base, uint64_t n, uint64_t total_bytes, int L, int W,
+                     uint64_t* d_words, uint32_t* d_lens, unsigned long long* d_bad, hipStream_t s) {
+  if (n == 0) return;
+  const dim3 g(grid_for(r, (n + 63) / 64 * 64, 256)), b(256);
+  if (d_off) hipLaunchKernelGGL(pack_nt2_tile_kernel<true>, g, b, 0, s, d_ascii, d_off, base, n, total_bytes, L, W, d_words, d_lens, d_bad);
+  else hipLaunchKernelGGL(pack_nt2_tile_kernel<false>, g, b, 0, s, d_ascii, d_off, base, n, total_bytes, L, W, d_words, d_lens, d_bad);
+  HIP_CHECK(hipGetLastError());
+}
+
 void launch_count_ascii(Replica& r, const uint8_t* d_q, const uint64_t* d_off, uint64_t n, uint64_t* d_counts,
                         uint64_t* d_ranges, uint8_t* d_status, hipStream_t s) {
   if (n == 0) return;
@@ -499,44 +512,50 @@ Replica::SurvScratch* surv_scratch(Replica& r, hipStream_t s) {
   return slot.get();
 }
 
+// d_lens != nullptr: read q has d_lens[q] letters (1..L) in its W = ceil(L / 32) words; else every read has L letters
 void launch_count_nt2_long(Replica& r, const uint64_t* d_words, uint64_t n, int L, uint64_t* d_counts, uint64_t* d_range_start,
-                           bool use_seed, hipStream_t s) {
+                           bool use_seed, hipStream_t s, const uint32_t* d_lens = nullptr) {
   require(r.dev.alphabet == NUCLEOTIDE, "packed 2-bit queries need a nucleotide index");
   require(r.dev.bwt_len < (1ull << 32) - 512, "the quad kernel needs bwt_len < 2^32");
   require(L >= 1 && L <= 1 << 20, "packed read length out of range");
   if (n == 0) return;
-  if (r.dev.text4 && r.dev.dense_ratio == 1) {
-    const bool sd = use_seed && r.seed_k > 0 && r.seed_k <= L;
-    const dim3 g(grid_for(r, n * 4, 256)), b(256);
-    const int om = count_kernel_override();
-    if (sd && L - r.seed_k >= 3 && L <= 512 && n < (1ull << 32) && (om < 0 || om == 3)) {
-      // two-phase: a per-lane pass settles the reads their seed entry (plus one SA read and one text window) decides,
-      // the quad kernel works through the rest
-      Replica::SurvScratch* sc = surv_scratch(r, s);
-      const unsigned nblk = (unsigned)r.num_cus * 8;  // both phases use this grid
-      const uint64_t per_block = ((n + (uint64_t)nblk * 256 - 1) / ((uint64_t)nblk * 256)) * 256;  // reads a block sees
-      if (sc->cap_q < per_block * nblk) {
-        HIP_CHECK(hipStreamSynchronize(s));
-        sc->q.alloc(per_block * nblk);
-        sc->cap_q = per_block * nblk;
-        sc->cap = 0;  // the k-mer path re-allocates its three lists together
-      }
-      if (!sc->count.p) sc->count.alloc(nblk);
-      const Nt2Survivors sv{nullptr, nullptr, sc->q.p, sc->count.p, per_block};
-      hipLaunchKernelGGL(count_nt2_reads_probe_kernel, dim3(nblk), b, 0, s, r.dev, d_words, n, L, d_counts, d_range_start, sv);
-      hipLaunchKernelGGL((count_nt2_reads_kernel<true, true, true>), dim3(nblk), b, 0, s, r.dev, d_words, n, L, d_counts, d_range_start, sv);
-      HIP_CHECK(hipGetLastError());
-      return;
+  const bool sd = use_seed && r.seed_k > 0 && (d_lens || r.seed_k <= L);  // ragged reads decide per read
+  const bool vfy = r.dev.text4 && r.dev.dense_ratio == 1;
+  const dim3 g(grid_for(r, n * 4, 256)), b(256);
+  const int om = count_kernel_override();
+  if (vfy && sd && L - r.seed_k >= 3 && L <= 512 && n < (1ull << 32) && (om < 0 || om == 3)) {
+    // two-phase: a per-lane pass settles the reads their seed entry (plus one SA read and one text window) decides,
+    // the quad kernel works through the rest
+    Replica::SurvScratch* sc = surv_scratch(r, s);
+    const unsigned nblk = (unsigned)r.num_cus * 8;  // both phases use this grid
+    const uint64_t per_block = ((n + (uint64_t)nblk * 256 - 1) / ((uint64_t)nblk * 256)) * 256;  // reads a block sees
+    if (sc->cap_q < per_block * nblk) {
+      HIP_CHECK(hipStreamSynchronize(s));
+      sc->q.alloc(per_block * nblk);
+      sc->cap_q = per_block * nblk;
+      sc->cap = 0;  // the k-mer path re-allocates its three lists together
     }
-    if (sd) hipLaunchKernelGGL((count_nt2_reads_kernel<true, true>), g, b, 0, s, r.dev, d_words, n, L, d_counts, d_range_start);
-    else hipLaunchKernelGGL((count_nt2_reads_kernel<false, true>), g, b, 0, s, r.dev, d_words, n, L, d_counts, d_range_start);
+    if (!sc->count.p) sc->count.alloc(nblk);
+    const Nt2Survivors sv{nullptr, nullptr, sc->q.p, sc->count.p, per_block};
+    if (d_lens) {
+      hipLaunchKernelGGL(count_nt2_reads_probe_kernel<true>, dim3(nblk), b, 0, s, r.dev, d_words, n, L, d_counts, d_range_start, sv, d_lens);
+      hipLaunchKernelGGL((count_nt2_reads_kernel<true, true, true, true>), dim3(nblk), b, 0, s, r.dev, d_words, n, L, d_counts, d_range_start, sv, d_lens);
+    } else {
+      hipLaunchKernelGGL(count_nt2_reads_probe_kernel<false>, dim3(nblk), b, 0, s, r.dev, d_words, n, L, d_counts, d_range_start, sv, d_lens);
+      hipLaunchKernelGGL((count_nt2_reads_kernel<true, true, true, false>), dim3(nblk), b, 0, s, r.dev, d_words, n, L, d_counts, d_range_start, sv, d_lens);
+    }
     HIP_CHECK(hipGetLastError());
     return;
   }
-  const bool seeded = use_seed && r.seed_k > 0 && r.seed_k <= L;
-  const dim3 g(grid_for(r, n * 4, 256)), b(256);
-  if (seeded) hipLaunchKernelGGL((count_nt2_reads_kernel<true, false>), g, b, 0, s, r.dev, d_words, n, L, d_counts, d_range_start);
-  else hipLaunchKernelGGL((count_nt2_reads_kernel<false, false>), g, b, 0, s, r.dev, d_words, n, L, d_counts, d_range_start);
+  const Nt2Survivors none{};
+#define AWRY_LAUNCH_READS(S, V)                                                                                                    \
+  do {                                                                                                                            \
+    if (d_lens) hipLaunchKernelGGL((count_nt2_reads_kernel<S, V, false, true>), g, b, 0, s, r.dev, d_words, n, L, d_counts, d_range_start, none, d_lens); \
+    else hipLaunchKernelGGL((count_nt2_reads_kernel<S, V, false, false>), g, b, 0, s, r.dev, d_words, n, L, d_counts, d_range_start, none, d_lens);       \
+  } while (0)
+  if (vfy) { if (sd) AWRY_LAUNCH_READS(true, true); else AWRY_LAUNCH_READS(false, true); }
+  else { if (sd) AWRY_LAUNCH_READS(true, false); else AWRY_LAUNCH_READS(false, false); }
+#undef AWRY_LAUNCH_READS
   HIP_CHECK(hipGetLastError());
 }
 
@@ -693,35 +712,75 @@ struct HostPin {
 // D2H counts) so transfers overlap kernels; no per-query offsets cross PCIe.  A chunk that turns out to hold
 // other bytes (N, IUPAC codes, '$' ...) is re-run through the generic kernel, so results never depend on the path.
 // The lane buffers persist in the replica (PackedLane), so a call costs no device allocation.
-bool shard_fixed_length(const uint64_t* qoff, Shard sh, uint64_t& L) {
-  if (sh.hi <= sh.lo) return false;
-  L = qoff[sh.lo + 1] - qoff[sh.lo];
-  if (L == 0 || L > 4096) return false;
+// Can a shard of queries take the packed kernels, and how?  uniform: every query has Lmax letters; ragged: lengths in
+// [1, Lmax], packed at a stride of W = ceil(Lmax / 32) words (accepted while that stride wastes little: the words of
+// a query may take up to ~2x its own bytes).  Whether the letters are all ACGT is found out on the device.
+struct PackedPlan {
+  bool ok = false, ragged = false;
+  uint64_t Lmax = 0;
+};
+PackedPlan plan_packed(const uint64_t* qoff, Shard sh) {
+  PackedPlan plan;
+  if (sh.hi <= sh.lo) return plan;
   const uint64_t n = sh.hi - sh.lo;
-  auto scan = [&](uint64_t lo, uint64_t hi) {
-    uint64_t diff = 0;  // branch-free so the loop vectorises
-    for (uint64_t i = lo; i < hi; i++) diff |= (qoff[i + 1] - qoff[i]) ^ L;
-    return diff == 0;
+  auto scan = [&](uint64_t lo, uint64_t hi, uint64_t& mn, uint64_t& mx) {  // branch-free so the loop vectorises
+    uint64_t a = ~0ull, b = 0;
+    for (uint64_t i = lo; i < hi; i++) {
+      const uint64_t d = qoff[i + 1] - qoff[i];
+      a = d < a ? d : a;
+      b = d > b ? d : b;
+    }
+    mn = a;
+    mx = b;
   };
-  if (!scan(sh.lo, sh.lo + std::min<uint64_t>(n, 4096))) return false;  // ragged batches leave here
+  uint64_t mn = ~0ull, mx = 0;
   const unsigned T = n >= (2u << 20) ? std::min(8u, std::max(1u, std::thread::hardware_concurrency())) : 1;
-  if (T == 1) return scan(sh.lo, sh.hi);
-  std::atomic<bool> ok{true};
-  std::vector<std::thread> th;
-  for (unsigned t = 0; t < T; t++)
-    th.emplace_back([&, t] { if (!scan(sh.lo + n * t / T, sh.lo + n * (t + 1) / T)) ok = false; });
-  for (auto& x : th) x.join();
-  return ok;
+  if (T == 1) {
+    scan(sh.lo, sh.hi, mn, mx);
+  } else {
+    std::vector<uint64_t> mns(T, ~0ull), mxs(T, 0);
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < T; t++) th.emplace_back([&, t] { scan(sh.lo + n * t / T, sh.lo + n * (t + 1) / T, mns[t], mxs[t]); });
+    for (auto& x : th) x.join();
+    for (unsigned t = 0; t < T; t++) { mn = std::min(mn, mns[t]); mx = std::max(mx, mxs[t]); }
+  }
+  if (mn == 0 || mx > 4096 || qoff[sh.hi] < qoff[sh.lo]) return plan;  // empty queries are the generic path's to reject
+  plan.Lmax = mx;
+  plan.ragged = mn != mx;
+  if (plan.ragged) {
+    const uint64_t bytes = qoff[sh.hi] - qoff[sh.lo], W = (mx + 31) / 32;
+    if (mx > 512 || W * 8 * n > 2 * bytes + 16 * n) return plan;
+  }
+  plan.ok = true;
+  return plan;
+}
+
+// chunks of a packed shard: at most max_q queries and ~max_bytes of ASCII each
+std::vector<Shard> packed_chunks(const uint64_t* qoff, Shard sh, uint64_t max_q, uint64_t max_bytes) {
+  std::vector<Shard> out;
+  uint64_t a = sh.lo;
+  while (a < sh.hi) {
+    uint64_t b = std::min(sh.hi, a + max_q);
+    if (qoff[b] - qoff[a] > max_bytes) {
+      b = (uint64_t)(std::upper_bound(qoff + a, qoff + b + 1, qoff[a] + max_bytes) - qoff) - 1;
+      b = std::max(b, a + 1);
+    }
+    out.push_back(Shard{a, b});
+    a = b;
+  }
+  return out;
 }
 
 void launch_count_nt2(Replica& r, const uint64_t* d_words, uint64_t n, int L, uint64_t* d_counts, bool use_seed, hipStream_t s,
                       unsigned long long* d_tally);
 void count_shard_generic(Replica& r, const uint8_t* qbytes, const uint64_t* qoff, Shard sh, uint64_t* counts_out);
 
-void count_shard_packed(Replica& r, const uint8_t* qbytes, const uint64_t* qoff, Shard sh, uint64_t L, uint64_t* counts_out) {
-  // queries per chunk: at most 4M, and at most 256 MiB of ASCII per lane
-  const uint64_t CH = std::max<uint64_t>(1u << 16, std::min<uint64_t>(4u << 20, (256ull << 20) / L));
+void count_shard_packed(Replica& r, const uint8_t* qbytes, const uint64_t* qoff, Shard sh, PackedPlan plan, uint64_t* counts_out) {
+  const uint64_t L = plan.Lmax;
   const int W = (int)((L + 31) / 32);
+  const std::vector<Shard> chunks = packed_chunks(qoff, sh, 4u << 20, 256ull << 20);
+  uint64_t cap_q = 0, cap_b = 0;
+  for (Shard c : chunks) { cap_q = std::max(cap_q, c.hi - c.lo); cap_b = std::max(cap_b, qoff[c.hi] - qoff[c.lo]); }
   static const bool trace = getenv("AWRY_TRACE_HOST") != nullptr;
   auto now = [] { return std::chrono::steady_clock::now(); };
   auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
@@ -738,7 +797,8 @@ void count_shard_packed(Replica& r, const uint8_t* qbytes, const uint64_t* qoff,
     std::thread& t;
     ~Joiner() { if (t.joinable()) t.join(); }
   } joiner{pin_out_thread};
-  HostPin pin_in(qbytes + qoff[sh.lo], (sh.hi - sh.lo) * L);
+  HostPin pin_in(qbytes + qoff[sh.lo], qoff[sh.hi] - qoff[sh.lo]);
+  HostPin pin_off(plan.ragged ? qoff + sh.lo : nullptr, (sh.hi - sh.lo + 1) * 8);
   const auto t1 = now();
   PackedLane* lanes = r.lanes;
   std::vector<Shard> redo;
@@ -761,26 +821,29 @@ void count_shard_packed(Replica& r, const uint8_t* qbytes, const uint64_t* qoff,
     ln.s = r.lane_stream[li];
     if (!ln.done) HIP_CHECK(hipEventCreateWithFlags(&ln.done, hipEventDisableTiming));
     if (!ln.h_bad) HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&ln.h_bad), 8, hipHostMallocDefault));
-    const uint64_t cap = std::min<uint64_t>(CH, sh.hi - sh.lo);
-    if (ln.ascii.n < cap * L + 16) ln.ascii.alloc(cap * L + 16);
-    if (ln.words.n < cap * W) ln.words.alloc(cap * W);
-    if (ln.counts.n < cap) ln.counts.alloc(cap);
+    if (ln.ascii.n < cap_b + 16) ln.ascii.alloc(cap_b + 16);
+    if (ln.words.n < cap_q * W) ln.words.alloc(cap_q * W);
+    if (ln.counts.n < cap_q) ln.counts.alloc(cap_q);
+    if (plan.ragged && ln.off.n < cap_q + 1) ln.off.alloc(cap_q + 1);
+    if (plan.ragged && ln.lens.n < cap_q) ln.lens.alloc(cap_q);
     if (!ln.bad.p) ln.bad.alloc(1);
   }
   const auto t2 = now();
   int which = 0;
-  for (uint64_t lo = sh.lo; lo < sh.hi; lo += CH, which ^= 1) {
+  for (Shard c : chunks) {
     PackedLane& ln = lanes[which];
+    which ^= 1;
     retire(ln);
-    const uint64_t hi = std::min(sh.hi, lo + CH), n = hi - lo;
+    const uint64_t lo = c.lo, hi = c.hi, n = hi - lo, nbytes = qoff[hi] - qoff[lo];
     ln.chunk_lo = lo;
     ln.chunk_hi = hi;
-    HIP_CHECK(hipMemcpyAsync(ln.ascii.p, qbytes + qoff[lo], n * L, hipMemcpyHostToDevice, ln.s));
+    HIP_CHECK(hipMemcpyAsync(ln.ascii.p, qbytes + qoff[lo], nbytes, hipMemcpyHostToDevice, ln.s));
+    if (plan.ragged) HIP_CHECK(hipMemcpyAsync(ln.off.p, qoff + lo, (n + 1) * 8, hipMemcpyHostToDevice, ln.s));
     HIP_CHECK(hipMemsetAsync(ln.bad.p, 0, 8, ln.s));
-    hipLaunchKernelGGL(pack_nt2_kernel, dim3(grid_for(r, n, 256)), dim3(256), 0, ln.s, ln.ascii.p, n, (int)L, ln.words.p, ln.bad.p);
-    HIP_CHECK(hipGetLastError());
-    if (L <= 32) launch_count_nt2(r, ln.words.p, n, (int)L, ln.counts.p, true, ln.s, nullptr);
-    else launch_count_nt2_long(r, ln.words.p, n, (int)L, ln.counts.p, nullptr, true, ln.s);
+    launch_pack_nt2(r, ln.ascii.p, plan.ragged ? ln.off.p : nullptr, qoff[lo], n, nbytes, (int)L, W, ln.words.p,
+                    plan.ragged ? ln.lens.p : nullptr, ln.bad.p, ln.s);
+    if (L <= 32 && !plan.ragged) launch_count_nt2(r, ln.words.p, n, (int)L, ln.counts.p, true, ln.s, nullptr);
+    else launch_count_nt2_long(r, ln.words.p, n, (int)L, ln.counts.p, nullptr, true, ln.s, plan.ragged ? ln.lens.p : nullptr);
     if (pin_out_thread.joinable()) pin_out_thread.join();
     HIP_CHECK(hipMemcpyAsync(counts_out + lo, ln.counts.p, n * 8, hipMemcpyDeviceToHost, ln.s));
     HIP_CHECK(hipMemcpyAsync(ln.h_bad, ln.bad.p, 8, hipMemcpyDeviceToHost, ln.s));
@@ -788,21 +851,21 @@ void count_shard_packed(Replica& r, const uint8_t* qbytes, const uint64_t* qoff,
     ln.busy = true;
   }
   for (int li = 0; li < 2; li++) retire(lanes[li]);
-  if (trace) fprintf(stderr, "[awry] packed shard %llu queries: pin %.2f ms, lane setup %.2f ms, pipeline %.2f ms\n",
-                     (unsigned long long)(sh.hi - sh.lo), ms(t0, t1), ms(t1, t2), ms(t2, now()));
+  if (trace) fprintf(stderr, "[awry] packed shard %llu queries%s: pin %.2f ms, lane setup %.2f ms, pipeline %.2f ms\n",
+                     (unsigned long long)(sh.hi - sh.lo), plan.ragged ? " (ragged)" : "", ms(t0, t1), ms(t1, t2), ms(t2, now()));
   for (Shard c : redo) count_shard_generic(r, qbytes, qoff, c, counts_out);  // also raises INVALID_QUERY where due
 }
 
 void count_shard(Replica& r, const uint8_t* qbytes, const uint64_t* qoff, Shard sh, uint64_t* counts_out) {
   HIP_CHECK(hipSetDevice(r.device));
-  uint64_t L = 0;
   static const bool no_fast = getenv("AWRY_HOST_PATH") && !strcmp(getenv("AWRY_HOST_PATH"), "generic");
   const auto t0 = std::chrono::steady_clock::now();
-  const bool fixed = !no_fast && r.dev.alphabet == NUCLEOTIDE && r.dev.bwt_len < (1ull << 32) - 512 && shard_fixed_length(qoff, sh, L);
+  PackedPlan plan;
+  if (!no_fast && r.dev.alphabet == NUCLEOTIDE && r.dev.bwt_len < (1ull << 32) - 512) plan = plan_packed(qoff, sh);
   if (getenv("AWRY_TRACE_HOST"))
-    fprintf(stderr, "[awry] fixed-length scan %.2f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
-  if (fixed) {
-    count_shard_packed(r, qbytes, qoff, sh, L, counts_out);
+    fprintf(stderr, "[awry] length scan %.2f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+  if (plan.ok) {
+    count_shard_packed(r, qbytes, qoff, sh, plan, counts_out);
     return;
   }
   count_shard_generic(r, qbytes, qoff, sh, counts_out);
@@ -906,13 +969,16 @@ void locate_shard_generic(Replica& r, const uint8_t* qbytes, const uint64_t* qof
 // (2) once the host knows the chunk's hit total: locate kernels, D2H of the positions into pinned staging; (3) copy
 // into the result arrays -- so that one chunk's transfers and host copies overlap the other chunk's kernels.  A chunk
 // that holds bytes outside ACGT is redone by the generic kernels; results never depend on the path.
-void locate_shard_packed(Replica& r, const uint8_t* qbytes, const uint64_t* qoff, Shard sh, uint64_t L, bool want_gpos, LocateResult& out) {
-  const uint64_t CH = std::max<uint64_t>(1u << 16, std::min<uint64_t>(1u << 20, (128ull << 20) / L));  // reads per chunk
-  const uint64_t W = (L + 31) / 32;
+void locate_shard_packed(Replica& r, const uint8_t* qbytes, const uint64_t* qoff, Shard sh, PackedPlan plan, bool want_gpos, LocateResult& out) {
+  const uint64_t L = plan.Lmax, W = (L + 31) / 32;
+  const std::vector<Shard> chunks = packed_chunks(qoff, sh, 1u << 20, 128ull << 20);
+  uint64_t cap = 0, cap_b = 0;
+  for (Shard c : chunks) { cap = std::max(cap, c.hi - c.lo); cap_b = std::max(cap_b, qoff[c.hi] - qoff[c.lo]); }
   static const bool trace = getenv("AWRY_TRACE_HOST") != nullptr;
   const auto t0 = std::chrono::steady_clock::now();
   std::lock_guard<std::mutex> lane_lock(r.lane_mu);
-  HostPin pin_in(qbytes + qoff[sh.lo], (sh.hi - sh.lo) * L);
+  HostPin pin_in(qbytes + qoff[sh.lo], qoff[sh.hi] - qoff[sh.lo]);
+  HostPin pin_off(plan.ragged ? qoff + sh.lo : nullptr, (sh.hi - sh.lo + 1) * 8);
   LocateLane* lanes = r.loc_lanes;
   struct Drain {  // every exit leaves the lanes idle before the input is unpinned
     Replica& r;
@@ -927,9 +993,10 @@ void locate_shard_packed(Replica& r, const uint8_t* qbytes, const uint64_t* qoff
     LocateLane& ln = lanes[li];
     if (!ln.counted) HIP_CHECK(hipEventCreateWithFlags(&ln.counted, hipEventDisableTiming));
     if (!ln.located) HIP_CHECK(hipEventCreateWithFlags(&ln.located, hipEventDisableTiming));
-    const uint64_t cap = std::min<uint64_t>(CH, sh.hi - sh.lo);
-    if (ln.ascii.n < cap * L + 16) ln.ascii.alloc(cap * L + 16);
+    if (ln.ascii.n < cap_b + 16) ln.ascii.alloc(cap_b + 16);
     if (ln.words.n < cap * W) ln.words.alloc(cap * W);
+    if (plan.ragged && ln.off.n < cap + 1) ln.off.alloc(cap + 1);
+    if (plan.ragged && ln.lens.n < cap) ln.lens.alloc(cap);
     if (ln.rstart.n < cap) ln.rstart.alloc(cap);
     if (ln.counts.n < cap) ln.counts.alloc(cap);
     if (ln.hit_off.n < cap + 1) ln.hit_off.alloc(cap + 1);
@@ -946,11 +1013,13 @@ void locate_shard_packed(Replica& r, const uint8_t* qbytes, const uint64_t* qoff
     ln.lo = lo;
     ln.hi = hi;
     ln.fallback = false;
-    HIP_CHECK(hipMemcpyAsync(ln.ascii.p, qbytes + qoff[lo], n * L, hipMemcpyHostToDevice, s));
+    const uint64_t nbytes = qoff[hi] - qoff[lo];
+    HIP_CHECK(hipMemcpyAsync(ln.ascii.p, qbytes + qoff[lo], nbytes, hipMemcpyHostToDevice, s));
+    if (plan.ragged) HIP_CHECK(hipMemcpyAsync(ln.off.p, qoff + lo, (n + 1) * 8, hipMemcpyHostToDevice, s));
     HIP_CHECK(hipMemsetAsync(ln.bad.p, 0, 8, s));
-    hipLaunchKernelGGL(pack_nt2_kernel, dim3(grid_for(r, n, 256)), dim3(256), 0, s, ln.ascii.p, n, (int)L, ln.words.p, ln.bad.p);
-    HIP_CHECK(hipGetLastError());
-    launch_count_nt2_long(r, ln.words.p, n, (int)L, ln.counts.p, ln.rstart.p, true, s);
+    launch_pack_nt2(r, ln.ascii.p, plan.ragged ? ln.off.p : nullptr, qoff[lo], n, nbytes, (int)L, (int)W, ln.words.p,
+                    plan.ragged ? ln.lens.p : nullptr, ln.bad.p, s);
+    launch_count_nt2_long(r, ln.words.p, n, (int)L, ln.counts.p, ln.rstart.p, true, s, plan.ragged ? ln.lens.p : nullptr);
     launch_scan(r, ln.counts.p, n, ln.hit_off.p, ln.scratch.p, s);
     HIP_CHECK(hipMemcpyAsync(ln.h_meta.p, ln.hit_off.p + n, 8, hipMemcpyDeviceToHost, s));
     HIP_CHECK(hipMemcpyAsync(ln.h_meta.p + 1, ln.bad.p, 8, hipMemcpyDeviceToHost, s));
@@ -999,11 +1068,12 @@ void locate_shard_packed(Replica& r, const uint8_t* qbytes, const uint64_t* qoff
     ln.stage = 0;
   };
   uint64_t i = 0;
-  for (uint64_t lo = sh.lo; lo < sh.hi; lo += CH, i++) {
+  for (Shard c : chunks) {
     const int li = (int)(i & 1);
-    stage3(li);                                   // chunk i - 2
-    stage1(li, lo, std::min(sh.hi, lo + CH));     // chunk i
-    stage2(li ^ 1);                               // chunk i - 1
+    stage3(li);              // chunk i - 2
+    stage1(li, c.lo, c.hi);  // chunk i
+    stage2(li ^ 1);          // chunk i - 1
+    i++;
   }
   const int last = (int)((i + 1) & 1);            // lane of chunk i - 1
   stage2(last);
@@ -1018,9 +1088,10 @@ void locate_shard(Replica& r, const uint8_t* qbytes, const uint64_t* qoff, Shard
   HIP_CHECK(hipSetDevice(r.device));
   out.nq = sh.hi - sh.lo;
   static const bool no_fast = getenv("AWRY_HOST_PATH") && !strcmp(getenv("AWRY_HOST_PATH"), "generic");
-  uint64_t L = 0;
-  if (!no_fast && r.dev.alphabet == NUCLEOTIDE && r.dev.bwt_len < (1ull << 32) - 512 && shard_fixed_length(qoff, sh, L))
-    locate_shard_packed(r, qbytes, qoff, sh, L, want_gpos, out);
+  PackedPlan plan;
+  if (!no_fast && r.dev.alphabet == NUCLEOTIDE && r.dev.bwt_len < (1ull << 32) - 512) plan = plan_packed(qoff, sh);
+  if (plan.ok)
+    locate_shard_packed(r, qbytes, qoff, sh, plan, want_gpos, out);
   else
     locate_shard_generic(r, qbytes, qoff, sh, want_gpos, out);
 }
@@ -1416,9 +1487,8 @@ int awry_dev_pack_nt2(awry_index_t* idx, int slot, const void* d_ascii, uint64_t
     require(L >= 1 && L <= (1 << 20), "packed read length out of range");
     require(d_ascii && d_words && d_bad, "null device pointer");
     if (n == 0) return;
-    hipLaunchKernelGGL(pack_nt2_kernel, dim3(grid_for(r, n, 256)), dim3(256), 0, (hipStream_t)stream,
-                       (const uint8_t*)d_ascii, n, L, (uint64_t*)d_words, (unsigned long long*)d_bad);
-    HIP_CHECK(hipGetLastError());
+    launch_pack_nt2(r, (const uint8_t*)d_ascii, nullptr, 0, n, n * (uint64_t)L, L, (L + 31) / 32, (uint64_t*)d_words, nullptr,
+                    (unsigned long long*)d_bad, (hipStream_t)stream);
   });
 }
 

@@ -23,7 +23,7 @@
 //   locate                LOCATE_TILE_KERNEL<A>          tiles of hits, per-lane walk state machines, dense SA
 //                         locate_scalar_kernel<A>        one hit per lane (round-1 baseline)
 //   accelerators          seed_level1/extend/finalize, densify_sa_kernel, text4_scatter_kernel
-//   glue                  pack_nt2_kernel, scan_*_kernel, ref_kmer_table_kernel, scalar_ops_kernel
+//   glue                  pack_nt2_tile_kernel, scan_*_kernel, ref_kmer_table_kernel, scalar_ops_kernel
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -1083,25 +1083,80 @@ __global__ __launch_bounds__(256) void aa_seed_finalize_kernel(DevIndex ix, Seed
   }
 }
 
-// ASCII fixed-length k-mers -> packed words; *bad counts queries with a byte outside ACGTacgt (U counts too:
-// the caller then takes the generic path, which applies the full alphabet map)
-__global__ __launch_bounds__(256) void pack_nt2_kernel(const uint8_t* __restrict__ ascii, uint64_t n, int L,
-                                                       uint64_t* __restrict__ words, unsigned long long* __restrict__ bad) {
-  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-  const int W = (L + 31) / 32;  // words per query: letter j in word j / 32, bits 2 (j % 32)
-  for (uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += stride) {
-    const uint8_t* p = ascii + q * (uint64_t)L;
-    uint64_t w = 0;
-    bool ok = true;
-    for (int j = 0; j < L; j++) {
-      uint8_t a = p[j] & 0xDF;  // upper-case
-      uint32_t c = a == 'A' ? 0u : (a == 'C' ? 1u : (a == 'G' ? 2u : (a == 'T' ? 3u : 4u)));
-      ok = ok && c < 4u && p[j] < 0x80;
-      w |= (uint64_t)(c & 3u) << (2 * (j & 31));
-      if ((j & 31) == 31 || j == L - 1) { words[q * W + (j >> 5)] = w; w = 0; }
+// ASCII queries -> packed words (letter j of a query in word j / 32, bits 2 (j % 32); W words per query, unused ones
+// zero); *bad counts queries with a byte outside ACGTacgt (U counts too: the caller then takes the generic path, which
+// applies the full alphabet map).  RAGGED: query q is ascii[off[q] - base, off[q + 1] - base) and its length goes to
+// lens[q]; otherwise every query has L bytes.
+//
+// A wave packs 64 consecutive queries at a time: their bytes are one contiguous range, fetched with coalesced 16-B
+// loads into the wave's LDS tile, from which every lane packs its own query (one query per lane reading its bytes
+// straight from global memory ran at 98 GB/s of ASCII).  Ranges that do not fit the tile are cut into fewer queries
+// per pass; a single query longer than the tile is packed from global memory by its lane.
+constexpr int PACK_TILE = 8192;  // bytes of LDS per wave
+template <bool RAGGED>
+__global__ __launch_bounds__(256) void pack_nt2_tile_kernel(const uint8_t* __restrict__ ascii, const uint64_t* __restrict__ off, uint64_t base,
+                                                            uint64_t n, uint64_t total_bytes, int L, int W, uint64_t* __restrict__ words,
+                                                            uint32_t* __restrict__ lens, unsigned long long* __restrict__ bad) {
+  const int64_t mis = (int64_t)(reinterpret_cast<uintptr_t>(ascii) & 15);  // tile chunks are 16-B aligned in memory
+  __shared__ __attribute__((aligned(16))) uint8_t s_tile[4][PACK_TILE + 16];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  uint8_t* tile = s_tile[wv];
+  const uint64_t nwaves = (uint64_t)gridDim.x * 4, wave0 = (uint64_t)blockIdx.x * 4 + wv;
+  uint32_t nbad = 0;
+  for (uint64_t q0 = wave0 * 64; q0 < n; q0 += nwaves * 64) {  // wave-uniform trip count
+    const uint64_t q = q0 + lane;
+    const bool have = q < n;
+    uint64_t s = 0, e = 0;  // this lane's query: bytes [s, e) of ascii
+    if (have) {
+      s = RAGGED ? off[q] - base : q * (uint64_t)L;
+      e = RAGGED ? off[q + 1] - base : s + (uint64_t)L;
     }
-    if (!ok) atomicAdd(bad, 1ull);
+    uint64_t done = 0;  // lanes [0, done) of this group of 64 are packed
+    const uint64_t nq = n - q0 < 64 ? n - q0 : 64;
+    while (done < nq) {
+      // the longest run of queries starting at lane `done` whose bytes fit the tile (measured from a 16-B aligned start)
+      const int64_t b0 = (int64_t)__shfl(s, (int)done, 64), a0 = ((b0 + mis) & ~15ll) - mis;  // may be < 0 by up to 15
+      const bool fits = have && (uint64_t)lane >= done && (int64_t)e - a0 <= (int64_t)PACK_TILE;
+      const uint64_t fm = __ballot(fits) >> done;
+      const int m = fm == ~0ull ? 64 : __builtin_ctzll(~fm);  // leading run of fitting lanes
+      const bool mine = (uint64_t)lane >= done && (uint64_t)lane < done + (m ? m : 1);
+      auto pack_from = [&](auto src) {  // src: this lane's query bytes, in LDS or in global memory
+        const int len = (int)(e - s);
+        uint64_t w = 0;
+        bool ok = true;
+        uint64_t* out = words + q * (uint64_t)W;
+        for (int j = 0; j < len; j++) {
+          const uint8_t raw = src[j], a = raw & 0xDF;  // upper-case
+          const uint32_t c = a == 'A' ? 0u : (a == 'C' ? 1u : (a == 'G' ? 2u : (a == 'T' ? 3u : 4u)));
+          ok = ok && c < 4u && raw < 0x80;
+          w |= (uint64_t)(c & 3u) << (2 * (j & 31));
+          if ((j & 31) == 31 || j == len - 1) { out[j >> 5] = w; w = 0; }
+        }
+        for (int k2 = (len + 31) >> 5; k2 < W; k2++) out[k2] = 0;
+        if (RAGGED) lens[q] = (uint32_t)len;
+        if (!ok) nbad++;
+      };
+      if (m > 0) {
+        const int64_t b1 = (int64_t)__shfl(e, (int)(done + m - 1), 64);
+        for (int64_t i = a0 + 16ll * lane; i < b1; i += 16ll * 64) {
+          if (i >= 0 && i + 16 <= (int64_t)total_bytes) {
+            *reinterpret_cast<uint4*>(tile + (i - a0)) = *reinterpret_cast<const uint4*>(ascii + i);
+          } else {  // first / last chunk of the buffer: only the bytes that exist
+            for (int t = 0; t < 16; t++)
+              if (i + t >= 0 && i + t < (int64_t)total_bytes) tile[i - a0 + t] = ascii[i + t];
+          }
+        }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        if (mine && have) pack_from(tile + ((int64_t)s - a0));
+      } else if (mine && have) {
+        pack_from(ascii + s);  // one query longer than the tile: its lane reads global memory directly
+      }
+      __builtin_amdgcn_wave_barrier();
+      done += m ? m : 1;
+    }
   }
+  if (nbad) atomicAdd(bad, (unsigned long long)nbad);
 }
 
 // Packed reads of any length (W = ceil(L/32) words per query, letter j in word j/32, bits 2(j%32)): the quad design
@@ -1115,10 +1170,11 @@ __global__ __launch_bounds__(256) void pack_nt2_kernel(const uint8_t* __restrict
 // locations are unchanged; the locate pass receives the verified candidates instead of a row range (RS_* words).
 // LIST: the quads of block b work through the reads block b of count_nt2_reads_probe_kernel left undecided
 // (sv.q / sv.count, same grid) instead of all n reads.
-template <bool USE_SEED, bool VERIFY, bool LIST = false>
+// RAGGED: read q has lens[q] letters (1 <= lens[q] <= L); L only sets the stride of W words per read.
+template <bool USE_SEED, bool VERIFY, bool LIST = false, bool RAGGED = false>
 __global__ __launch_bounds__(256) void count_nt2_reads_kernel(DevIndex ix, const uint64_t* __restrict__ queries, uint64_t n, int L,
                                                               uint64_t* __restrict__ counts, uint64_t* __restrict__ range_start,
-                                                              Nt2Survivors sv = Nt2Survivors{}) {
+                                                              Nt2Survivors sv = Nt2Survivors{}, const uint32_t* __restrict__ lens = nullptr) {
   const int l = threadIdx.x & 3;
   const uint64_t nquads = ((uint64_t)gridDim.x * blockDim.x) >> 2;
   const uint64_t region = LIST ? (uint64_t)blockIdx.x * sv.cap : 0;
@@ -1147,24 +1203,26 @@ __global__ __launch_bounds__(256) void count_nt2_reads_kernel(DevIndex ix, const
       uint64_t out_count = 0, out_rs = 0;
       if (mode == 0) {
         if (fresh) {
-          const int first = L - k;  // letters first .. L-1 form the seed window (leftmost letter least significant)
+          const int Lq = RAGGED ? (int)lens[q] : L;
+          const bool seeded = USE_SEED && (!RAGGED || Lq >= k);  // a read shorter than the seed starts without the table
+          const int first = seeded ? Lq - k : 0;  // letters first .. Lq-1 form the seed window (leftmost letter least significant)
           const int a = first >> 5, sh = 2 * (first & 31);
           uint64_t win = qw[a] >> sh;
           if (sh && a + 1 < W) win |= qw[a + 1] << (64 - sh);
           SeedEntry e{1u, 0u};
           uint32_t scnt = SEED_CNT_SAT;
-          if (USE_SEED) {
+          if (seeded) {
             e = seed[(win & ((1ull << (2 * k)) - 1))];
             scnt = seed_cnt(e);
             sp = scnt ? e.sp : 1u;
             ep = scnt ? e.sp + scnt - 1u : 0u;
             i = first;
           }
-          if (!USE_SEED || scnt == SEED_CNT_SAT) {  // no table, or a count the entry cannot represent
-            const uint32_t c = (uint32_t)(qw[(L - 1) >> 5] >> (2 * ((L - 1) & 31))) & 3u;  // SearchRange::new(last letter)
+          if (!seeded || scnt == SEED_CNT_SAT) {  // no table, or a count the entry cannot represent
+            const uint32_t c = (uint32_t)(qw[(Lq - 1) >> 5] >> (2 * ((Lq - 1) & 31))) & 3u;  // SearchRange::new(last letter)
             sp = c == 0 ? cA : (c == 1 ? cC : (c == 2 ? cG : cT));
             ep = (c == 0 ? cC : (c == 1 ? cG : (c == 2 ? cN : cEnd))) - 1;
-            i = L - 1;
+            i = Lq - 1;
           }
           steps_done = 0;
           w = i > 0 ? qw[(i - 1) >> 5] : 0;
@@ -1232,10 +1290,12 @@ __global__ __launch_bounds__(256) void count_nt2_reads_kernel(DevIndex ix, const
 // singleton with the right symbol is one candidate, settled by SA[sp] and the L - k letters of text in front of it
 // (queued in LDS so that full waves issue those loads, as in count_nt2_probe_kernel); the rest (2+ rows, saturated
 // entries) goes to block-private lists that count_nt2_reads_kernel<.., LIST> works through with the quad machinery.
-// Results are those of count_nt2_reads_kernel<true, true> (counts and RS_* range-start words).
+// Results are those of count_nt2_reads_kernel<true, true> (counts and RS_* range-start words).  RAGGED: read q has
+// lens[q] letters; reads with fewer than 3 letters left of their seed window go to the lists unprobed.
+template <bool RAGGED>
 __global__ __launch_bounds__(256) void count_nt2_reads_probe_kernel(DevIndex ix, const uint64_t* __restrict__ queries, uint64_t n, int L,
                                                                     uint64_t* __restrict__ counts, uint64_t* __restrict__ range_start,
-                                                                    Nt2Survivors sv) {
+                                                                    Nt2Survivors sv, const uint32_t* __restrict__ lens) {
   constexpr int VQ = 192;
   __shared__ unsigned int s_count;
   __shared__ uint32_t s_vsp[4][VQ], s_vq[4][VQ];
@@ -1243,10 +1303,7 @@ __global__ __launch_bounds__(256) void count_nt2_reads_probe_kernel(DevIndex ix,
   __syncthreads();
   const int lane = threadIdx.x & 63, wv_id = threadIdx.x >> 6;
   const SeedEntry* __restrict__ seed = ix.seed;
-  const int k = ix.seed_k, i0 = L - k, W = (L + 31) / 32;
-  const int wa = i0 >> 5, wsh = 2 * (i0 & 31);            // seed window: letters i0 .. L-1
-  const int na = (i0 - 1) >> 5, nsh = 2 * ((i0 - 1) & 31);  // the letter in front of it
-  const int nchunks = (i0 + 31) >> 5;
+  const int k = ix.seed_k, W = (L + 31) / 32;  // RAGGED: L is the longest read, W the stride
   const uint64_t kmask = (1ull << (2 * k)) - 1;
   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
   const uint64_t lane_lt = (1ull << lane) - 1;
@@ -1270,6 +1327,7 @@ __global__ __launch_bounds__(256) void count_nt2_reads_probe_kernel(DevIndex ix,
 #pragma unroll
     for (int h = 0; h < 2; h++) {
       if (!on[h]) continue;
+      const int i0 = (RAGGED ? (int)lens[q[h]] : L) - k, nchunks = (i0 + 31) >> 5;
       uint32_t bad = vp[h] >= (uint32_t)i0 ? 0u : 1u;  // else the suffix starts too close to the text's beginning
       const uint64_t g = (uint64_t)vp[h] - (uint64_t)i0;
       const uint64_t* qw = queries + (uint64_t)q[h] * W;
@@ -1282,23 +1340,31 @@ __global__ __launch_bounds__(256) void count_nt2_reads_probe_kernel(DevIndex ix,
   for (uint64_t wbase = (uint64_t)blockIdx.x * blockDim.x + (threadIdx.x & ~63u); wbase < n; wbase += NQ * stride) {
     uint64_t qv[NQ], win[NQ];
     uint32_t nc[NQ];
+    bool probe[NQ];  // false: too short for the per-lane path (fewer than 3 letters left of the seed window)
     SeedEntry ev[NQ];
 #pragma unroll
     for (int h = 0; h < NQ; h++) {
       qv[h] = wbase + lane + (uint64_t)h * stride;
       win[h] = 0;
       nc[h] = 0;
+      probe[h] = false;
       if (qv[h] < n) {
-        const uint64_t* qw = queries + qv[h] * W;
-        win[h] = qw[wa] >> wsh;
-        if (wsh && wa + 1 < W) win[h] |= qw[wa + 1] << (64 - wsh);
-        nc[h] = (uint32_t)(qw[na] >> nsh) & 3u;
+        const int i0 = (RAGGED ? (int)lens[qv[h]] : L) - k;
+        probe[h] = i0 >= 3;
+        if (probe[h]) {
+          const uint64_t* qw = queries + qv[h] * W;
+          const int wa = i0 >> 5, wsh = 2 * (i0 & 31);            // seed window: letters i0 .. L-1
+          const int na = (i0 - 1) >> 5, nsh = 2 * ((i0 - 1) & 31);  // the letter in front of it
+          win[h] = qw[wa] >> wsh;
+          if (wsh && wa + 1 < W) win[h] |= qw[wa + 1] << (64 - wsh);
+          nc[h] = (uint32_t)(qw[na] >> nsh) & 3u;
+        }
       }
     }
 #pragma unroll
     for (int h = 0; h < NQ; h++) {
       ev[h] = SeedEntry{1u, 0u};
-      if (qv[h] < n) ev[h] = seed[win[h] & kmask];
+      if (probe[h]) ev[h] = seed[win[h] & kmask];
     }
 #pragma unroll
     for (int h = 0; h < NQ; h++) {
@@ -1306,7 +1372,9 @@ __global__ __launch_bounds__(256) void count_nt2_reads_probe_kernel(DevIndex ix,
       const SeedEntry e = ev[h];
       const uint32_t cnt = seed_cnt(e);
       bool survivor = false, queued = false;
-      if (valid) {
+      if (valid && !probe[h]) {
+        survivor = true;
+      } else if (valid) {
         if (cnt == 0u) settle(qv[h], 0, (RS_PLAIN << RS_MODE_SHIFT) | 1ull);
         else if (cnt == 1u) {
           queued = seed_sym(e) == (int)(nc[h] == 3u ? 5u : nc[h] + 1u);

@@ -469,6 +469,51 @@ def test_two_phase_reads_schedule_matches_single_kernel_and_oracle(oracle, L):
         ix.set_verify(-1)
 
 
+@pytest.mark.parametrize("lo,hi", [(1, 40), (20, 40), (60, 160), (5, 330), (33, 35)])
+def test_ragged_batches_take_the_packed_kernels(oracle, lo, hi, monkeypatch):
+    """batches of unequal lengths (trimmed reads): packed on the device at a common stride, per-read lengths through
+    the two-phase read kernels -- counts, locations and their order are the oracle's, for reads shorter than the seed,
+    with and without the seed-and-verify accelerators, and equal to the generic path's"""
+    text, st, hd = synth.make_text(300000, 0, 1000 + lo, 3, 0.03)
+    ix = gpu_index(text, 0, 8, 0, st, hd)
+    oi = oracle.OracleIndex.from_text(text, 0, 8, 0, st, hd)
+    rng = np.random.default_rng(lo * 1000 + hi)
+    nq = 6000
+    lens = rng.integers(lo, hi + 1, size=nq)
+    starts = rng.integers(0, len(text) - hi - 2, size=nq)
+    qs = []
+    for i in range(nq):
+        q = text[starts[i]:starts[i] + lens[i]].copy()
+        kind = i % 4
+        if kind == 1:  # random letters
+            q = synth.NT[rng.integers(0, 4, size=lens[i])]
+        elif kind == 2:  # one substitution
+            j = int(rng.integers(0, lens[i]))
+            q[j] = synth.NT[(int(np.searchsorted(synth.NT, q[j])) + 1) % 4] if q[j] in synth.NT else ord("A")
+        if not np.isin(q, synth.NT).all():
+            q = synth.NT[rng.integers(0, 4, size=lens[i])]
+        qs.append(q)
+    qb = np.concatenate(qs)
+    qo = np.zeros(nq + 1, dtype=np.uint64)
+    qo[1:] = np.cumsum(lens)
+    ooff, ogpos, opos, _ = oi.parallel_locate(qb, qo, 4)
+    for verify in (-1, 0, 2):
+        ix.set_verify(verify)
+        for k in (-1, 6, 12):
+            ix.set_seed_kmer_len(k)
+            assert np.array_equal(ix.parallel_count_csr(qb, qo), np.diff(ooff)), (verify, k)
+            off, g, p = ix.parallel_locate_csr(qb, qo)
+            assert np.array_equal(off, ooff) and np.array_equal(g, ogpos) and np.array_equal(p, opos), (verify, k)
+    # a batch with a few reads holding N / lower case falls back to the generic kernels chunk-wise: same answers
+    qb2 = qb.copy()
+    qb2[int(qo[17])] = ord("N")
+    qb2[int(qo[4000]):int(qo[4001])] = np.frombuffer(bytes(qb2[int(qo[4000]):int(qo[4001])]).lower(), dtype=np.uint8)
+    ooff2, ogpos2, _, _ = oi.parallel_locate(qb2, qo, 4)
+    off, g, _ = ix.parallel_locate_csr(qb2, qo)
+    assert np.array_equal(off, ooff2) and np.array_equal(g, ogpos2)
+    assert np.array_equal(ix.parallel_count_csr(qb2, qo), np.diff(ooff2))
+
+
 def test_locate_walks_next_to_long_n_runs(oracle):
     """row sampling + N runs: inside a run LF moves by a constant stride (the number of runs at least that long), so a
     walk that enters a run at a row of the wrong residue meets no sampled row until the run ends -- tens of thousands of

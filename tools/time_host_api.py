@@ -22,4 +22,4 @@ qo = np.zeros(len(lens) + 1, dtype=np.uint64); qo[1:] = np.cumsum(lens)
 qb = synth.NT[np.random.default_rng(2).integers(0, 4, size=int(qo[-1]), dtype=np.uint8)]
 for rep in range(2):
     t = time.perf_counter(); c = ix.parallel_count_csr(qb, qo); dt = time.perf_counter() - t
-print("ragged 20..39: %d queries in %.1f ms -> %.1f M queries/s (generic kernel)" % (len(lens), dt * 1e3, len(lens) / dt / 1e6))
+print("ragged 20..39: %d queries in %.1f ms -> %.1f M queries/s (ragged packed path)" % (len(lens), dt * 1e3, len(lens) / dt / 1e6))

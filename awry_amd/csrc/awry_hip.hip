@@ -86,7 +86,7 @@ struct PackedLane {
   hipEvent_t done = nullptr;
   DevBuf<uint8_t> ascii;
   DevBuf<uint64_t> words, counts, off;  // off / lens: batches of unequal lengths
-  DevBuf<uint32_t> lens;
+  DevBuf<uint32_t> lens, bad_list;      // bad_list: the chunk's queries with bytes outside ACGT
   DevBuf<unsigned long long> bad;
   unsigned long long* h_bad = nullptr;  // pinned
   uint64_t chunk_lo = 0, chunk_hi = 0;
@@ -122,7 +122,10 @@ struct LocateLane {
   hipEvent_t counted = nullptr, located = nullptr;
   DevBuf<uint8_t> ascii;
   DevBuf<uint64_t> words, rstart, counts, hit_off, scratch, gpos, pos, off;
-  DevBuf<uint32_t> lens;
+  DevBuf<uint32_t> lens, bad_list;
+  std::vector<uint32_t> h_list;                // sorted chunk-relative indices of the queries redone by the generic kernels
+  std::vector<uint64_t> sub_counts;            //   and their hit counts
+  bool merge = false;                          // some of them have hits: stage 3 interleaves the two result sets
   DevBuf<unsigned long long> bad;
   PinBuf<uint64_t> h_counts, h_gpos, h_meta;  // h_meta: [0] total hits of the chunk, [1] reads with bytes outside ACGT
   PinBuf<awry_pos_t> h_pos;
@@ -363,11 +366,11 @@ std::unique_ptr<Replica> make_replica(awry_index* ix, int device) {
 // ASCII -> packed 2-bit words.  d_off == nullptr: n queries of L bytes each; else query q = bytes [d_off[q] - base, d_off[q+1] - base)
 // of d_ascii (total_bytes in all), W words per query (stride), lengths to d_lens.
 void launch_pack_nt2(Replica& r, const uint8_t* d_ascii, const uint64_t* d_off, uint64_t base, uint64_t n, uint64_t total_bytes, int L, int W,
-                     uint64_t* d_words, uint32_t* d_lens, unsigned long long* d_bad, hipStream_t s) {
+                     uint64_t* d_words, uint32_t* d_lens, unsigned long long* d_bad, hipStream_t s, uint32_t* d_bad_list = nullptr) {
   if (n == 0) return;
   const dim3 g(grid_for(r, (n + 63) / 64 * 64, 256)), b(256);
-  if (d_off) hipLaunchKernelGGL(pack_nt2_tile_kernel<true>, g, b, 0, s, d_ascii, d_off, base, n, total_bytes, L, W, d_words, d_lens, d_bad);
-  else hipLaunchKernelGGL(pack_nt2_tile_kernel<false>, g, b, 0, s, d_ascii, d_off, base, n, total_bytes, L, W, d_words, d_lens, d_bad);
+  if (d_off) hipLaunchKernelGGL(pack_nt2_tile_kernel<true>, g, b, 0, s, d_ascii, d_off, base, n, total_bytes, L, W, d_words, d_lens, d_bad, d_bad_list);
+  else hipLaunchKernelGGL(pack_nt2_tile_kernel<false>, g, b, 0, s, d_ascii, d_off, base, n, total_bytes, L, W, d_words, d_lens, d_bad, d_bad_list);
   HIP_CHECK(hipGetLastError());
 }
 
@@ -688,11 +691,12 @@ void run_count_chunk(Replica& r, ChunkBuffers& cb, const uint8_t* qbytes, const 
   HIP_CHECK(hipMemcpyAsync(cb.h_status.data(), cb.status.p, n, hipMemcpyDeviceToHost, r.stream));
 }
 
-void check_status(const ChunkBuffers& cb, uint64_t first_query) {
+// names[i] (if given) is the batch index of the chunk's query i -- for sub-batches gathered out of a larger one
+void check_status(const ChunkBuffers& cb, uint64_t first_query, const uint64_t* names = nullptr) {
   for (size_t i = 0; i < cb.h_status.size(); i++)
     if (cb.h_status[i] != Q_OK) {
       static const char* why[] = {"", "empty query", "query contains '$' or '#'", "query contains a non-ASCII byte"};
-      throw QueryError("query " + std::to_string(first_query + i) + ": " + why[cb.h_status[i] & 3] +
+      throw QueryError("query " + std::to_string(names ? names[first_query + i] : first_query + i) + ": " + why[cb.h_status[i] & 3] +
                        " (undefined in the reference: src/fm_index.rs:406, src/bwt.rs:126-128)");
     }
 }
@@ -773,7 +777,23 @@ std::vector<Shard> packed_chunks(const uint64_t* qoff, Shard sh, uint64_t max_q,
 
 void launch_count_nt2(Replica& r, const uint64_t* d_words, uint64_t n, int L, uint64_t* d_counts, bool use_seed, hipStream_t s,
                       unsigned long long* d_tally);
-void count_shard_generic(Replica& r, const uint8_t* qbytes, const uint64_t* qoff, Shard sh, uint64_t* counts_out);
+void count_shard_generic(Replica& r, const uint8_t* qbytes, const uint64_t* qoff, Shard sh, uint64_t* counts_out,
+                         const uint64_t* names = nullptr);
+
+// The queries `idx` (sorted batch indices) gathered into a batch of their own: bytes, offsets and batch indices.
+struct SubBatch {
+  std::vector<uint8_t> bytes;
+  std::vector<uint64_t> off, names;
+  SubBatch(const uint8_t* qbytes, const uint64_t* qoff, uint64_t base, const std::vector<uint32_t>& idx) {
+    off.assign(1, 0);
+    for (uint32_t i : idx) {
+      const uint64_t q = base + i;
+      bytes.insert(bytes.end(), qbytes + qoff[q], qbytes + qoff[q + 1]);
+      off.push_back(bytes.size());
+      names.push_back(q);
+    }
+  }
+};
 
 void count_shard_packed(Replica& r, const uint8_t* qbytes, const uint64_t* qoff, Shard sh, PackedPlan plan, uint64_t* counts_out) {
   const uint64_t L = plan.Lmax;
@@ -801,12 +821,19 @@ void count_shard_packed(Replica& r, const uint8_t* qbytes, const uint64_t* qoff,
   HostPin pin_off(plan.ragged ? qoff + sh.lo : nullptr, (sh.hi - sh.lo + 1) * 8);
   const auto t1 = now();
   PackedLane* lanes = r.lanes;
-  std::vector<Shard> redo;
+  std::vector<Shard> redo;                                          // chunks redone whole,
+  std::vector<std::pair<uint64_t, std::vector<uint32_t>>> redo_sub;  // (chunk start, sorted indices) redone query by query
   auto retire = [&](PackedLane& ln) {
     if (!ln.busy) return;
     ln.busy = false;
     HIP_CHECK(hipEventSynchronize(ln.done));
-    if (*ln.h_bad) redo.push_back(Shard{ln.chunk_lo, ln.chunk_hi});
+    const uint64_t nb = *ln.h_bad, n = ln.chunk_hi - ln.chunk_lo;
+    if (nb == 0) return;
+    if (nb > n / 8) { redo.push_back(Shard{ln.chunk_lo, ln.chunk_hi}); return; }  // mostly other letters: not worth sorting out
+    std::vector<uint32_t> idx(nb);
+    HIP_CHECK(hipMemcpy(idx.data(), ln.bad_list.p, nb * 4, hipMemcpyDeviceToHost));  // the lane is idle: the list is final
+    std::sort(idx.begin(), idx.end());
+    redo_sub.emplace_back(ln.chunk_lo, std::move(idx));
   };
   // every exit, normal or not, leaves the lanes idle before the host ranges are unpinned
   struct Drain {
@@ -826,6 +853,7 @@ void count_shard_packed(Replica& r, const uint8_t* qbytes, const uint64_t* qoff,
     if (ln.counts.n < cap_q) ln.counts.alloc(cap_q);
     if (plan.ragged && ln.off.n < cap_q + 1) ln.off.alloc(cap_q + 1);
     if (plan.ragged && ln.lens.n < cap_q) ln.lens.alloc(cap_q);
+    if (ln.bad_list.n < cap_q) ln.bad_list.alloc(cap_q);
     if (!ln.bad.p) ln.bad.alloc(1);
   }
   const auto t2 = now();
@@ -841,7 +869,7 @@ void count_shard_packed(Replica& r, const uint8_t* qbytes, const uint64_t* qoff,
     if (plan.ragged) HIP_CHECK(hipMemcpyAsync(ln.off.p, qoff + lo, (n + 1) * 8, hipMemcpyHostToDevice, ln.s));
     HIP_CHECK(hipMemsetAsync(ln.bad.p, 0, 8, ln.s));
     launch_pack_nt2(r, ln.ascii.p, plan.ragged ? ln.off.p : nullptr, qoff[lo], n, nbytes, (int)L, W, ln.words.p,
-                    plan.ragged ? ln.lens.p : nullptr, ln.bad.p, ln.s);
+                    plan.ragged ? ln.lens.p : nullptr, ln.bad.p, ln.s, ln.bad_list.p);
     if (L <= 32 && !plan.ragged) launch_count_nt2(r, ln.words.p, n, (int)L, ln.counts.p, true, ln.s, nullptr);
     else launch_count_nt2_long(r, ln.words.p, n, (int)L, ln.counts.p, nullptr, true, ln.s, plan.ragged ? ln.lens.p : nullptr);
     if (pin_out_thread.joinable()) pin_out_thread.join();
@@ -853,7 +881,14 @@ void count_shard_packed(Replica& r, const uint8_t* qbytes, const uint64_t* qoff,
   for (int li = 0; li < 2; li++) retire(lanes[li]);
   if (trace) fprintf(stderr, "[awry] packed shard %llu queries%s: pin %.2f ms, lane setup %.2f ms, pipeline %.2f ms\n",
                      (unsigned long long)(sh.hi - sh.lo), plan.ragged ? " (ragged)" : "", ms(t0, t1), ms(t1, t2), ms(t2, now()));
-  for (Shard c : redo) count_shard_generic(r, qbytes, qoff, c, counts_out);  // also raises INVALID_QUERY where due
+  // queries with other bytes (N, IUPAC codes, '$' ...): the generic kernel, which also raises INVALID_QUERY where due
+  for (Shard c : redo) count_shard_generic(r, qbytes, qoff, c, counts_out);
+  for (auto& rs : redo_sub) {
+    SubBatch sb(qbytes, qoff, rs.first, rs.second);
+    std::vector<uint64_t> tmp(rs.second.size());
+    count_shard_generic(r, sb.bytes.data(), sb.off.data(), Shard{0, rs.second.size()}, tmp.data(), sb.names.data());
+    for (size_t i = 0; i < tmp.size(); i++) counts_out[rs.first + rs.second[i]] = tmp[i];
+  }
 }
 
 void count_shard(Replica& r, const uint8_t* qbytes, const uint64_t* qoff, Shard sh, uint64_t* counts_out) {
@@ -871,14 +906,14 @@ void count_shard(Replica& r, const uint8_t* qbytes, const uint64_t* qoff, Shard 
   count_shard_generic(r, qbytes, qoff, sh, counts_out);
 }
 
-void count_shard_generic(Replica& r, const uint8_t* qbytes, const uint64_t* qoff, Shard sh, uint64_t* counts_out) {
+void count_shard_generic(Replica& r, const uint8_t* qbytes, const uint64_t* qoff, Shard sh, uint64_t* counts_out, const uint64_t* names) {
   HIP_CHECK(hipSetDevice(r.device));
   ChunkBuffers cb;
   for (Shard c : chunk_queries(qoff, sh.lo, sh.hi)) {
     run_count_chunk(r, cb, qbytes, qoff, c, false);
     HIP_CHECK(hipMemcpyAsync(counts_out + c.lo, cb.counts.p, (c.hi - c.lo) * 8, hipMemcpyDeviceToHost, r.stream));
     HIP_CHECK(hipStreamSynchronize(r.stream));
-    check_status(cb, c.lo);
+    check_status(cb, c.lo, names);
   }
 }
 
@@ -932,7 +967,7 @@ struct LocateResult {  // per shard, in query order
 
 // generic kernels, synchronous: any alphabet, ragged lengths, ambiguity codes
 void locate_chunk_generic(Replica& r, const uint8_t* qbytes, const uint64_t* qoff, Shard c, uint64_t* counts_out,
-                          std::vector<uint64_t>& gpos, std::vector<awry_pos_t>& pos) {
+                          std::vector<uint64_t>& gpos, std::vector<awry_pos_t>& pos, const uint64_t* names = nullptr) {
   ChunkBuffers cb;
   const uint64_t n = c.hi - c.lo;
   run_count_chunk(r, cb, qbytes, qoff, c, true);
@@ -942,7 +977,7 @@ void locate_chunk_generic(Replica& r, const uint8_t* qbytes, const uint64_t* qof
   HIP_CHECK(hipMemcpyAsync(&total, hit_off.p + n, 8, hipMemcpyDeviceToHost, r.stream));
   HIP_CHECK(hipMemcpyAsync(counts_out, cb.counts.p, n * 8, hipMemcpyDeviceToHost, r.stream));
   HIP_CHECK(hipStreamSynchronize(r.stream));
-  check_status(cb, c.lo);
+  check_status(cb, c.lo, names);
   gpos.resize(total);
   pos.resize(total);
   if (total == 0) return;
@@ -997,6 +1032,7 @@ void locate_shard_packed(Replica& r, const uint8_t* qbytes, const uint64_t* qoff
     if (ln.words.n < cap * W) ln.words.alloc(cap * W);
     if (plan.ragged && ln.off.n < cap + 1) ln.off.alloc(cap + 1);
     if (plan.ragged && ln.lens.n < cap) ln.lens.alloc(cap);
+    if (ln.bad_list.n < cap) ln.bad_list.alloc(cap);
     if (ln.rstart.n < cap) ln.rstart.alloc(cap);
     if (ln.counts.n < cap) ln.counts.alloc(cap);
     if (ln.hit_off.n < cap + 1) ln.hit_off.alloc(cap + 1);
@@ -1013,13 +1049,18 @@ void locate_shard_packed(Replica& r, const uint8_t* qbytes, const uint64_t* qoff
     ln.lo = lo;
     ln.hi = hi;
     ln.fallback = false;
+    ln.merge = false;
+    ln.h_list.clear();
     const uint64_t nbytes = qoff[hi] - qoff[lo];
     HIP_CHECK(hipMemcpyAsync(ln.ascii.p, qbytes + qoff[lo], nbytes, hipMemcpyHostToDevice, s));
     if (plan.ragged) HIP_CHECK(hipMemcpyAsync(ln.off.p, qoff + lo, (n + 1) * 8, hipMemcpyHostToDevice, s));
     HIP_CHECK(hipMemsetAsync(ln.bad.p, 0, 8, s));
     launch_pack_nt2(r, ln.ascii.p, plan.ragged ? ln.off.p : nullptr, qoff[lo], n, nbytes, (int)L, (int)W, ln.words.p,
-                    plan.ragged ? ln.lens.p : nullptr, ln.bad.p, s);
+                    plan.ragged ? ln.lens.p : nullptr, ln.bad.p, s, ln.bad_list.p);
     launch_count_nt2_long(r, ln.words.p, n, (int)L, ln.counts.p, ln.rstart.p, true, s, plan.ragged ? ln.lens.p : nullptr);
+    // reads with other bytes count as "no hits" in this pass; stage 2 redoes them with the generic kernels
+    hipLaunchKernelGGL(zero_listed_counts_kernel, dim3(64), dim3(256), 0, s, ln.bad_list.p, ln.bad.p, ln.counts.p);
+    HIP_CHECK(hipGetLastError());
     launch_scan(r, ln.counts.p, n, ln.hit_off.p, ln.scratch.p, s);
     HIP_CHECK(hipMemcpyAsync(ln.h_meta.p, ln.hit_off.p + n, 8, hipMemcpyDeviceToHost, s));
     HIP_CHECK(hipMemcpyAsync(ln.h_meta.p + 1, ln.bad.p, 8, hipMemcpyDeviceToHost, s));
@@ -1033,7 +1074,17 @@ void locate_shard_packed(Replica& r, const uint8_t* qbytes, const uint64_t* qoff
     hipStream_t s = r.lane_stream[li];
     const uint64_t n = ln.hi - ln.lo;
     HIP_CHECK(hipEventSynchronize(ln.counted));
-    if (ln.h_meta.p[1]) {  // bytes outside ACGT: the generic kernels redo this chunk (and raise INVALID_QUERY where due)
+    const uint64_t nb = ln.h_meta.p[1];
+    if (nb && nb <= n / 8) {  // a few reads with other bytes (N, IUPAC codes ...): the generic kernels redo just those
+      ln.h_list.resize(nb);
+      HIP_CHECK(hipMemcpy(ln.h_list.data(), ln.bad_list.p, nb * 4, hipMemcpyDeviceToHost));  // final: the lane's stream is idle
+      std::sort(ln.h_list.begin(), ln.h_list.end());
+      SubBatch sb(qbytes, qoff, ln.lo, ln.h_list);
+      ln.sub_counts.resize(nb);
+      locate_chunk_generic(r, sb.bytes.data(), sb.off.data(), Shard{0, nb}, ln.sub_counts.data(), ln.fb_gpos, ln.fb_pos, sb.names.data());
+      for (uint64_t i = 0; i < nb; i++) ln.h_counts.p[ln.h_list[i]] = ln.sub_counts[i];  // they were zero in the packed pass
+      ln.merge = !ln.fb_pos.empty();
+    } else if (nb) {  // mostly other bytes: the generic kernels redo the chunk (and raise INVALID_QUERY where due)
       ln.fb_counts.resize(n);
       locate_chunk_generic(r, qbytes, qoff, Shard{ln.lo, ln.hi}, ln.fb_counts.data(), ln.fb_gpos, ln.fb_pos);
       out.add_counts(ln.fb_counts.data(), n);
@@ -1063,7 +1114,25 @@ void locate_shard_packed(Replica& r, const uint8_t* qbytes, const uint64_t* qoff
       out.append(ln.fb_gpos.data(), ln.fb_pos.data(), ln.fb_pos.size(), want_gpos);
     } else {
       HIP_CHECK(hipEventSynchronize(ln.located));
-      out.append(ln.h_gpos.p, ln.h_pos.p, ln.total, want_gpos);
+      if (!ln.merge) {
+        out.append(ln.h_gpos.p, ln.h_pos.p, ln.total, want_gpos);
+      } else {  // rare: interleave the packed pass's hits with those of the reads the generic kernels redid, in query order
+        const uint64_t n = ln.hi - ln.lo;
+        std::vector<awry_pos_t> mp(ln.total + ln.fb_pos.size());
+        std::vector<uint64_t> mg(want_gpos ? mp.size() : 0);
+        size_t pk = 0, fb = 0, w = 0, bi = 0;
+        for (uint64_t q = 0; q < n; q++) {
+          const uint64_t c = ln.h_counts.p[q];
+          const bool redone = bi < ln.h_list.size() && ln.h_list[bi] == q;
+          if (redone) bi++;
+          if (!c) continue;
+          memcpy(mp.data() + w, redone ? ln.fb_pos.data() + fb : ln.h_pos.p + pk, c * sizeof(awry_pos_t));
+          if (want_gpos) memcpy(mg.data() + w, redone ? ln.fb_gpos.data() + fb : ln.h_gpos.p + pk, c * 8);
+          (redone ? fb : pk) += c;
+          w += c;
+        }
+        out.append(mg.data(), mp.data(), w, want_gpos);
+      }
     }
     ln.stage = 0;
   };

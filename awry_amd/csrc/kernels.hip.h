@@ -1084,8 +1084,9 @@ __global__ __launch_bounds__(256) void aa_seed_finalize_kernel(DevIndex ix, Seed
 }
 
 // ASCII queries -> packed words (letter j of a query in word j / 32, bits 2 (j % 32); W words per query, unused ones
-// zero); *bad counts queries with a byte outside ACGTacgt (U counts too: the caller then takes the generic path, which
-// applies the full alphabet map).  RAGGED: query q is ascii[off[q] - base, off[q + 1] - base) and its length goes to
+// zero); *bad counts queries with a byte outside ACGTacgt and bad_list (if given, room for n entries) names them, in
+// no particular order (U counts too: the caller redoes those queries with the generic kernel, which applies the full
+// alphabet map).  RAGGED: query q is ascii[off[q] - base, off[q + 1] - base) and its length goes to
 // lens[q]; otherwise every query has L bytes.
 //
 // A wave packs 64 consecutive queries at a time: their bytes are one contiguous range, fetched with coalesced 16-B
@@ -1096,13 +1097,13 @@ constexpr int PACK_TILE = 8192;  // bytes of LDS per wave
 template <bool RAGGED>
 __global__ __launch_bounds__(256) void pack_nt2_tile_kernel(const uint8_t* __restrict__ ascii, const uint64_t* __restrict__ off, uint64_t base,
                                                             uint64_t n, uint64_t total_bytes, int L, int W, uint64_t* __restrict__ words,
-                                                            uint32_t* __restrict__ lens, unsigned long long* __restrict__ bad) {
+                                                            uint32_t* __restrict__ lens, unsigned long long* __restrict__ bad,
+                                                            uint32_t* __restrict__ bad_list) {
   const int64_t mis = (int64_t)(reinterpret_cast<uintptr_t>(ascii) & 15);  // tile chunks are 16-B aligned in memory
   __shared__ __attribute__((aligned(16))) uint8_t s_tile[4][PACK_TILE + 16];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   uint8_t* tile = s_tile[wv];
   const uint64_t nwaves = (uint64_t)gridDim.x * 4, wave0 = (uint64_t)blockIdx.x * 4 + wv;
-  uint32_t nbad = 0;
   for (uint64_t q0 = wave0 * 64; q0 < n; q0 += nwaves * 64) {  // wave-uniform trip count
     const uint64_t q = q0 + lane;
     const bool have = q < n;
@@ -1134,7 +1135,10 @@ __global__ __launch_bounds__(256) void pack_nt2_tile_kernel(const uint8_t* __res
         }
         for (int k2 = (len + 31) >> 5; k2 < W; k2++) out[k2] = 0;
         if (RAGGED) lens[q] = (uint32_t)len;
-        if (!ok) nbad++;
+        if (!ok) {  // rare: the caller redoes this query with the generic kernel
+          const unsigned long long at = atomicAdd(bad, 1ull);
+          if (bad_list) bad_list[at] = (uint32_t)q;
+        }
       };
       if (m > 0) {
         const int64_t b1 = (int64_t)__shfl(e, (int)(done + m - 1), 64);
@@ -1156,7 +1160,14 @@ __global__ __launch_bounds__(256) void pack_nt2_tile_kernel(const uint8_t* __res
       done += m ? m : 1;
     }
   }
-  if (nbad) atomicAdd(bad, (unsigned long long)nbad);
+}
+
+// counts[list[i]] = 0 for the *count queries the pack kernel listed (their packed words are meaningless; locate must
+// not expand hits for them before the generic kernel has redone them)
+__global__ __launch_bounds__(256) void zero_listed_counts_kernel(const uint32_t* __restrict__ list, const unsigned long long* __restrict__ count,
+                                                                 uint64_t* __restrict__ counts) {
+  const uint64_t m = *count, stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += stride) counts[list[i]] = 0;
 }
 
 // Packed reads of any length (W = ceil(L/32) words per query, letter j in word j/32, bits 2(j%32)): the quad design

@@ -82,6 +82,8 @@ int awry_seed_kmer_len(const awry_index_t *idx);
 /* A/B switch for the packed-k-mer count kernel (process-wide; -1 policy, 0 strided quads, 1 LDS-staged chunks,
  * 2 groups of four queries per quad, 3 two-phase probe + resume).  All variants return identical counts. */
 int awry_debug_set_count_kernel(int mode);
+/* device pointer of replica `slot`'s dense SA (u32 SA[j * ratio]) or NULL -- for tests that dump it */
+const void *awry_debug_dense_sa(const awry_index_t *idx, int slot);
 /* name(s) of the kernel(s) awry_dev_count_nt2 launches for k-mers of length L on replica 0 (for profiling reports) */
 const char *awry_count_schedule(const awry_index_t *idx, int L);
 /* device-side SA sampling used by locate (performance knob only; locations do not depend on it): 0 = walk to the
@@ -91,12 +93,13 @@ int awry_set_locate_sa_ratio(awry_index_t *idx, int ratio);
 int awry_locate_sa_ratio(const awry_index_t *idx);
 /* seed-and-verify for packed nucleotide reads (performance knob only; counts and locations do not depend on it):
  * keeps the ratio-1 dense SA and the text as 4-bit codes in HBM (GRCh38: 12.4 + 1.55 GB), both recovered from the
- * index on the device.  Once a range holds <= 8 rows and `after_steps` LF steps have run, the rest of the read is
- * compared with the text in front of each candidate instead of being matched by one dependent LF step per symbol.
- * after_steps = -1 switches it off.  Default policy (awry_set_devices): on with after_steps = 2 for nucleotide indexes
- * with bwt_len < 2^32 whose accelerators fit in half of the free HBM; env AWRY_VERIFY=0 disables, =N sets after_steps.
- * It applies to reads (awry_dev_count_nt2_long, the host fast paths for L > 32); the k-mer kernel (L <= 32) uses it only
- * after awry_set_verify_kmers(idx, 1), because on random k-mer batches the extra state costs ~15 %. */
+ * index on the device.  Once a range holds a single row -- or <= 8 rows after `after_steps` LF steps -- the rest of the
+ * query is compared with the text in front of each candidate instead of being matched by one dependent LF step per
+ * symbol.  after_steps = -1 switches it off.  Default policy (awry_set_devices): on with after_steps = 2 for nucleotide
+ * indexes with bwt_len < 2^32 whose accelerators fit in half of the free HBM; env AWRY_VERIFY=0 disables, =N sets
+ * after_steps.  Used by the read kernels (awry_dev_count_nt2_long, the host paths) and by the two-phase k-mer schedule;
+ * the single-kernel k-mer schedule (dense seed tables) uses it only after awry_set_verify_kmers(idx, 1), because there
+ * the extra state costs random batches ~15 %. */
 int awry_set_verify(awry_index_t *idx, int after_steps);
 int awry_set_verify_kmers(awry_index_t *idx, int on);
 int awry_verify_enabled(const awry_index_t *idx);

@@ -266,6 +266,7 @@ void build_seed(awry_index* ix, Replica& r, int k) {
   r.seed_k = 0;
   r.dev.seed = nullptr;
   r.dev.seed_k = 0;
+  r.dev.seed_pos = 0;
   if (k <= 0) return;
   require(narrow(ix->host), "seed table needs an index with bwt_len < 2^32");
   const bool nt = ix->host.alphabet == NUCLEOTIDE;
@@ -299,6 +300,27 @@ void build_seed(awry_index* ix, Replica& r, int k) {
 void build_dense_sa(awry_index* ix, Replica& r, int ratio);
 void build_verify(awry_index* ix, Replica& r, int after_steps);
 void refresh_nblock(awry_index* ix, Replica& r);
+
+// Position seeds are kept exactly while they pay: nucleotide replica with the verify accelerators resident and a table
+// sparse enough for the two-phase schedules (the kernels of those schedules settle a singleton from the text and never
+// need its row; the other schedules and the generic kernel would have to start such queries over without the table).
+// Called after anything that changes the table or the accelerators.  AWRY_SEED_POS=0 keeps rows.
+void sync_seed_mode(awry_index* ix, Replica& r) {
+  const HostIndex& h = ix->host;
+  static const bool off = getenv("AWRY_SEED_POS") && !strcmp(getenv("AWRY_SEED_POS"), "0");
+  const bool want = !off && h.alphabet == NUCLEOTIDE && narrow(h) && r.seed_k > 0 && r.seed.p && r.dev.text4 && r.dense_ratio == 1 &&
+                    r.dense_sa.p && (1ull << (2 * r.seed_k)) / 3 >= h.bwt_len;
+  if (want == (r.dev.seed_pos != 0)) return;
+  if (!want) {  // rows again: rebuild (the row of a position is not recoverable without an inverse SA)
+    build_seed(ix, r, r.seed_k);
+    return;
+  }
+  const uint64_t nfinal = 1ull << (2 * r.seed_k);
+  hipLaunchKernelGGL(seed_rows_to_positions_kernel, dim3(grid_for(r, nfinal, 256)), dim3(256), 0, r.stream, r.seed.p, nfinal, r.dense_sa.p);
+  HIP_CHECK(hipGetLastError());
+  HIP_CHECK(hipStreamSynchronize(r.stream));
+  r.dev.seed_pos = 1;
+}
 
 std::unique_ptr<Replica> make_replica(awry_index* ix, int device) {
   int ndev = 0;
@@ -344,6 +366,7 @@ std::unique_ptr<Replica> make_replica(awry_index* ix, int device) {
   d.dense_ratio = 0;
   d.verify_after = 0;
   d.sa_nblock = nullptr;
+  d.seed_pos = 0;
   build_seed(ix, *r, ix->seed_k_request < 0 ? default_seed_k(h) : ix->seed_k_request);
   build_dense_sa(ix, *r, ix->dense_ratio_request);
   int vreq = ix->verify_request;
@@ -358,6 +381,7 @@ std::unique_ptr<Replica> make_replica(awry_index* ix, int device) {
   if (vreq >= 0) build_verify(ix, *r, vreq);
   r->verify_kmers = ix->verify_kmers_request;
   refresh_nblock(ix, *r);
+  sync_seed_mode(ix, *r);
   return r;
 }
 
@@ -1343,6 +1367,7 @@ int awry_set_seed_kmer_len(awry_index_t* idx, int k) {
     for (size_t s = 0; s < idx->reps.size(); s++) {
       Replica& r = replica(idx, (int)s);
       build_seed(idx, r, k < 0 ? default_seed_k(idx->host) : k);
+      sync_seed_mode(idx, r);
     }
   });
 }
@@ -1596,6 +1621,7 @@ int awry_set_locate_sa_ratio(awry_index_t* idx, int ratio) {
     for (size_t s = 0; s < idx->reps.size(); s++) {
       build_dense_sa(idx, replica(idx, (int)s), ratio);
       refresh_nblock(idx, replica(idx, (int)s));
+      sync_seed_mode(idx, replica(idx, (int)s));
     }
   });
 }
@@ -1608,6 +1634,7 @@ int awry_set_verify(awry_index_t* idx, int after_steps) {
     for (size_t s = 0; s < idx->reps.size(); s++) {
       build_verify(idx, replica(idx, (int)s), after_steps);
       refresh_nblock(idx, replica(idx, (int)s));
+      sync_seed_mode(idx, replica(idx, (int)s));
     }
   });
 }

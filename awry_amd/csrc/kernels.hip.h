@@ -180,12 +180,15 @@ __global__ __launch_bounds__(256) void count_scalar_kernel(DevIndex ix, const ui
         if (acgt) {
           const SeedEntry se = ix.seed[sidx];
           const uint32_t scnt = seed_cnt(se);
-          if (scnt != SEED_CNT_SAT) {
+          const bool wrong_sym = scnt == 1 && e - k > b && seed_sym(se) != (int)lut[ascii[e - k - 1]];  // BWT[row] is not the next symbol
+          // position seeds (ix.seed_pos): a singleton entry names a text position, not a row -- good enough to reject
+          // the query by its symbol, not to continue the search: such a query starts without the table
+          if (scnt != SEED_CNT_SAT && !(ix.seed_pos && scnt == 1 && !wrong_sym)) {
             sp = scnt ? se.sp : 1;
             ep = scnt ? (uint64_t)se.sp + scnt - 1 : 0;
             i = e - k;
             seeded = true;
-            if (scnt == 1 && i > b && seed_sym(se) != (int)lut[ascii[i - 1]]) { sp = 1; ep = 0; }  // BWT[sp] is not the next symbol
+            if (wrong_sym) { sp = 1; ep = 0; }
           }
         }
       }
@@ -461,7 +464,8 @@ __global__ __launch_bounds__(256) void count_nt2_quad_kernel(DevIndex ix, const 
             const uint32_t nc = (uint32_t)(w >> (2 * (i - 1))) & 3u;
             if (seed_sym(e) != (int)(nc == 3u ? 5u : nc + 1u)) { sp = 1u; ep = 0u; }
           }
-          if (scnt == SEED_CNT_SAT) i = -1;  // count not representable: start this query without the table
+          // count not representable, or a position seed (ix.seed_pos) that would have to be stepped: start without the table
+          if (scnt == SEED_CNT_SAT || (ix.seed_pos && scnt == 1u && sp <= ep && i > 0)) i = -1;
           if (TALLY) t_probe++;
         }
         if (!USE_SEED || i < 0) {
@@ -600,7 +604,8 @@ __global__ __launch_bounds__(256) void count_nt2_quad4_kernel(DevIndex ix, const
               const uint32_t nc = (uint32_t)(w >> (2 * (i - 1))) & 3u;
               if (seed_sym(e) != (int)(nc == 3u ? 5u : nc + 1u)) { sp = 1u; ep = 0u; }
             }
-            if (scnt == SEED_CNT_SAT) i = -1;  // count not representable: start this query without the table
+            // count not representable, or a position seed (ix.seed_pos) that would have to be stepped: start without the table
+            if (scnt == SEED_CNT_SAT || (ix.seed_pos && scnt == 1u && sp <= ep && i > 0)) i = -1;
             if (TALLY) t_probe++;
           }
           if (!USE_SEED || i < 0) {
@@ -705,7 +710,8 @@ __global__ __launch_bounds__(256) void count_nt2_probe_kernel(DevIndex ix, const
   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
   const uint64_t lane_lt = (1ull << lane) - 1;
   const uint64_t region = (uint64_t)blockIdx.x * sv.cap;
-  const bool verify = VERIFY && i0 >= 3;
+  const bool pos = VERIFY && ix.seed_pos;   // singleton entries hold SA[row]: no SA read, and no row to step from
+  const bool verify = VERIFY && (i0 >= 3 || (pos && i0 >= 1));
   int vcount = 0;  // wave-uniform fill of this wave's queue
   uint32_t t_vsa = 0, t_vtxt = 0;
   auto drain = [&](int base, int cnt) {  // entries [base, base + cnt) of the queue, cnt <= 128: two per lane
@@ -718,8 +724,9 @@ __global__ __launch_bounds__(256) void count_nt2_probe_kernel(DevIndex ix, const
       on[h] = lane + 64 * h < cnt;
       w[h] = on[h] ? s_vw[VERIFY ? wv_id : 0][s] : 0;
       q[h] = on[h] ? s_vq[VERIFY ? wv_id : 0][s] : 0;
-      vp[h] = on[h] ? ix.dense_sa[s_vsp[VERIFY ? wv_id : 0][s]] : 0;
-      if (TALLY && on[h]) t_vsa++;
+      vp[h] = on[h] ? s_vsp[VERIFY ? wv_id : 0][s] : 0;
+      if (!pos && on[h]) vp[h] = ix.dense_sa[vp[h]];
+      if (TALLY && on[h] && !pos) t_vsa++;
     }
 #pragma unroll
     for (int h = 0; h < 2; h++) {
@@ -965,7 +972,7 @@ __global__ __launch_bounds__(256) void count_nt2_chunk_kernel(DevIndex ix, const
               const uint32_t nc = (uint32_t)(w >> (2 * (i - 1))) & 3u;
               if (seed_sym(e) != (int)(nc == 3u ? 5u : nc + 1u)) { sp = 1u; ep = 0u; }
             }
-            if (scnt == SEED_CNT_SAT) i = -1;
+            if (scnt == SEED_CNT_SAT || (ix.seed_pos && scnt == 1u && sp <= ep && i > 0)) i = -1;
             if (TALLY) t_probe++;
           }
           if (!USE_SEED || i < 0) {
@@ -1041,6 +1048,18 @@ __global__ __launch_bounds__(256) void seed_finalize_kernel(DevIndex ix, SeedEnt
     else if (e.cnt >= SEED_CNT_SAT) e.cnt = SEED_CNT_SAT;
     else continue;
     table[o] = e;
+  }
+}
+
+// Position seeds (DevIndex::seed_pos): every singleton entry's row is replaced by the text position of that row's
+// suffix.  A query whose seed window occurs once in the text then needs no SA read: the entry itself says where the
+// single candidate is, and the text decides (2 random lines per such query instead of 3).
+__global__ __launch_bounds__(256) void seed_rows_to_positions_kernel(SeedEntry* __restrict__ table, uint64_t nentries,
+                                                                     const uint32_t* __restrict__ dense_sa) {
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t o = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; o < nentries; o += stride) {
+    const SeedEntry e = table[o];
+    if (seed_cnt(e) == 1u) table[o].sp = dense_sa[e.sp];
   }
 }
 
@@ -1207,6 +1226,7 @@ __global__ __launch_bounds__(256) void count_nt2_reads_kernel(DevIndex ix, const
   // verify state (quad-uniform): mode 0 = LF steps, 1 = read SA of candidate vj, 2 = compare text chunk vc
   int mode = 0, vj = 0, vc = 0;
   uint32_t vmask = 0, vp = 0;
+  bool pos_hit = false;  // position seed whose window is the whole read
   while (__any(have)) {
     if (have) {
       const uint64_t* qw = queries + q * W;
@@ -1241,6 +1261,26 @@ __global__ __launch_bounds__(256) void count_nt2_reads_kernel(DevIndex ix, const
             const uint32_t nc = (uint32_t)(w >> (2 * ((i - 1) & 31))) & 3u;
             if (seed_sym(e) != (int)(nc == 3u ? 5u : nc + 1u)) { sp = 1u; ep = 0u; }
           }
+          if (seeded && ix.seed_pos && scnt == 1u && sp <= ep) {
+            // position seed: e.sp is SA[row], the text position of the single candidate -- there is no row to step from
+            if (i == 0) {  // the read is the seed window itself
+              pos_hit = true;
+              vp = e.sp;
+            } else if (VERIFY && i < 65536) {  // straight to the text, no SA read
+              vp = e.sp;
+              sp = ep = 0u;  // one candidate, index 0
+              vj = 0;
+              vmask = 0;
+              if (vp >= (uint32_t)i) { mode = 2; vc = 0; }
+              else { mode = 1; vj = 1; }  // too close to the text's beginning: no match (finishes below)
+            } else {  // start again without the table
+              const uint32_t c = (uint32_t)(qw[(Lq - 1) >> 5] >> (2 * ((Lq - 1) & 31))) & 3u;
+              sp = c == 0 ? cA : (c == 1 ? cC : (c == 2 ? cG : cT));
+              ep = (c == 0 ? cC : (c == 1 ? cG : (c == 2 ? cN : cEnd))) - 1;
+              i = Lq - 1;
+              w = i > 0 ? qw[(i - 1) >> 5] : 0;
+            }
+          }
           fresh = false;
         } else {
           i--;
@@ -1250,7 +1290,14 @@ __global__ __launch_bounds__(256) void count_nt2_reads_kernel(DevIndex ix, const
           steps_done++;
           if ((i & 31) == 0 && i > 0) w = qw[(i - 1) >> 5];
         }
-        if (sp > ep || i == 0) {
+        if (pos_hit) {
+          finished = true;
+          pos_hit = false;
+          out_count = 1;
+          out_rs = (RS_SINGLE << RS_MODE_SHIFT) | (uint64_t)vp;
+        } else if (mode != 0) {
+          // a position seed went straight to the text
+        } else if (sp > ep || i == 0) {
           finished = true;
           out_count = sp > ep ? 0ull : (uint64_t)(ep - sp) + 1ull;
           out_rs = (RS_PLAIN << RS_MODE_SHIFT) | sp;
@@ -1315,6 +1362,8 @@ __global__ __launch_bounds__(256) void count_nt2_reads_probe_kernel(DevIndex ix,
   const int lane = threadIdx.x & 63, wv_id = threadIdx.x >> 6;
   const SeedEntry* __restrict__ seed = ix.seed;
   const int k = ix.seed_k, W = (L + 31) / 32;  // RAGGED: L is the longest read, W the stride
+  const bool pos = ix.seed_pos != 0;           // singleton entries hold SA[row]: no SA read, and no row to step from
+  const int min_i0 = pos ? 1 : 3;              // fewest letters left of the seed window worth (or, with pos, needing) the text
   const uint64_t kmask = (1ull << (2 * k)) - 1;
   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
   const uint64_t lane_lt = (1ull << lane) - 1;
@@ -1333,7 +1382,7 @@ __global__ __launch_bounds__(256) void count_nt2_reads_probe_kernel(DevIndex ix,
       on[h] = lane + 64 * h < cnt;
       q[h] = on[h] ? s_vq[wv_id][s] : 0;
       sp[h] = on[h] ? s_vsp[wv_id][s] : 0;
-      vp[h] = on[h] ? ix.dense_sa[sp[h]] : 0;
+      vp[h] = on[h] ? (pos ? sp[h] : ix.dense_sa[sp[h]]) : 0;
     }
 #pragma unroll
     for (int h = 0; h < 2; h++) {
@@ -1361,7 +1410,7 @@ __global__ __launch_bounds__(256) void count_nt2_reads_probe_kernel(DevIndex ix,
       probe[h] = false;
       if (qv[h] < n) {
         const int i0 = (RAGGED ? (int)lens[qv[h]] : L) - k;
-        probe[h] = i0 >= 3;
+        probe[h] = i0 >= min_i0;
         if (probe[h]) {
           const uint64_t* qw = queries + qv[h] * W;
           const int wa = i0 >> 5, wsh = 2 * (i0 & 31);            // seed window: letters i0 .. L-1

@@ -423,8 +423,9 @@ def test_per_lane_verify_of_the_two_phase_schedule(oracle):
                 assert np.array_equal(ix.count_kmers_nt2(q2d[:nq], True), want[:nq]), (L, k, nq)
             got, census = ix.count_kmers_nt2(q2d, True, tally=True)
             assert np.array_equal(got, want) and int(census[0]) == len(q2d)
-            # the text settled (at least) the present and the near-miss k-mers, unless the window is too short to bother
-            assert (int(census[4]) >= 3000) == (i0 >= 3), (L, k, census)
+            # the text settled (at least) the present and the near-miss k-mers: with position seeds (this table is sparse
+            # enough for them) however few letters are left of the seed window
+            assert int(census[4]) >= 3000, (L, k, census)
         assert "probe" in ix.count_schedule(31)
     finally:
         L_.awry_debug_set_count_kernel(-1)

@@ -293,6 +293,10 @@ def main():
         if tentry:
             result["roofline"]["traffic"] = tentry["traffic_bytes_per_launch"]
             result["roofline"]["traffic_source"] = tentry["source"]
+            # the HBM bytes the kernel really moves per second (PMC traffic / live kernel time): every 8-B seed entry drags a
+            # whole line, so this sits far above the algorithmic rate
+            result["roofline"]["traffic_GBs"] = tentry["traffic_bytes_per_launch"] / (kernel_ms * 1e-3) / 1e9
+            result["roofline"]["traffic_frac_of_peak"] = result["roofline"]["traffic_GBs"] / HBM_PEAK_GBS
     except (OSError, ValueError):
         pass
     # the ceiling that actually binds this access pattern: random 128-B line requests (profiles/r01_gather_calibration.txt)

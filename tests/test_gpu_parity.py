@@ -276,6 +276,41 @@ def test_host_batch_fast_path_equals_generic(oracle, L, monkeypatch):
     assert e.value.code == ERR_INVALID_QUERY
 
 
+def test_host_pipelines_over_many_chunks(oracle):
+    """batches larger than one pipeline chunk (count: 4 M queries, locate: 1 M reads) alternate between the two stream
+    lanes; a sprinkling of reads with N goes through the per-read fallback in every chunk.  Checked against the oracle
+    on a random sample of the queries and, for the rest, through count = number of locations"""
+    text, st, hd = synth.make_text(600000, 0, 88, 2, 0.02)
+    ix = gpu_index(text, 0, 8, 0, st, hd)
+    oi = oracle.OracleIndex.from_text(text, 0, 8, 0, st, hd)
+    rng = np.random.default_rng(8)
+    for ragged in (False, True):
+        nq = 4_500_000
+        lens = rng.integers(18, 31, size=nq) if ragged else np.full(nq, 24)
+        qo = np.zeros(nq + 1, dtype=np.uint64)
+        qo[1:] = np.cumsum(lens)
+        starts = rng.integers(0, len(text) - 40, size=nq)
+        idx = np.repeat(starts, lens) + (np.arange(int(qo[-1])) - np.repeat(qo[:-1].astype(np.int64), lens))
+        qb = text[idx].copy()
+        rnd = rng.random(nq) < 0.3  # 30 % random letters instead of a window of the text
+        rmask = np.repeat(rnd, lens)
+        qb[rmask] = synth.NT[rng.integers(0, 4, size=int(rmask.sum()))]
+        qb[qb == ord("$")] = ord("A")
+        counts = ix.parallel_count_csr(qb, qo)
+        off, g, p = ix.parallel_locate_csr(qb, qo)
+        assert np.array_equal(np.diff(off), counts) and len(g) == int(off[-1]) == len(p)
+        sample = np.sort(rng.choice(nq, size=20000, replace=False))
+        sb = np.concatenate([qb[int(qo[i]):int(qo[i + 1])] for i in sample])
+        so = np.zeros(len(sample) + 1, dtype=np.uint64)
+        so[1:] = np.cumsum(lens[sample])
+        ooff, ogpos, opos, _ = oi.parallel_locate(sb, so, 4)
+        assert np.array_equal(np.diff(ooff), counts[sample])
+        got_g = np.concatenate([g[int(off[i]):int(off[i + 1])] for i in sample])
+        got_p = np.concatenate([p[int(off[i]):int(off[i + 1])] for i in sample])
+        assert np.array_equal(got_g, ogpos) and np.array_equal(got_p, opos)
+        assert (counts[~rnd] >= 1).all() or (qb == ord("N")).any()  # windows of the text are found (N windows match too)
+
+
 @pytest.mark.parametrize("n,recs", [(248_956_422, 1), (3_100_000_000, 25)], ids=["chr1_scale", "grch38_scale"])
 def test_full_scale_properties(n, recs):
     """BASELINE.json's full sizes (index built on the GPU in seconds): size-independent properties.

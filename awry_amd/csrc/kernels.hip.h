@@ -679,6 +679,8 @@ __global__ __launch_bounds__(256) void count_nt2_quad4_kernel(DevIndex ix, const
 //     probes per wave instruction and two queries in flight per lane -- no dependent chain beyond query -> entry;
 //     queries that need LF steps are appended (wave ballot + one atomic per wave) to a compact survivor list;
 //   phase 2 (count_nt2_resume_kernel): the quad machinery on the survivors only, resuming from the probed range.
+constexpr int VMULTI = 4;  // seed ranges of up to this many rows are verified candidate by candidate in phase 1
+
 struct Nt2Survivors {
   uint64_t* w;                 // query words
   uint64_t* range;             // sp | cnt << 32 as probed (cnt == SEED_CNT_SAT: restart without the table)
@@ -700,7 +702,8 @@ __global__ __launch_bounds__(256) void count_nt2_probe_kernel(DevIndex ix, const
   constexpr int VQ = 192;                          // queue slots per wave: drained 128 at a time, two per lane
   __shared__ uint64_t s_vw[VERIFY ? 4 : 1][VQ];   // per-wave verify queue: query word,
   __shared__ uint32_t s_vsp[VERIFY ? 4 : 1][VQ];  //   candidate row,
-  __shared__ uint32_t s_vq[VERIFY ? 4 : 1][VQ];   //   query index
+  __shared__ uint32_t s_vq[VERIFY ? 4 : 1][VQ];   //   query index,
+  __shared__ uint8_t s_vn[VERIFY ? 4 : 1][VQ];    //   number of candidate rows (1..VMULTI)
   if (threadIdx.x == 0) s_count = 0;
   __syncthreads();
   const int lane = threadIdx.x & 63, wv_id = threadIdx.x >> 6;
@@ -716,7 +719,7 @@ __global__ __launch_bounds__(256) void count_nt2_probe_kernel(DevIndex ix, const
   uint32_t t_vsa = 0, t_vtxt = 0;
   auto drain = [&](int base, int cnt) {  // entries [base, base + cnt) of the queue, cnt <= 128: two per lane
     uint64_t w[2];
-    uint32_t q[2], vp[2];
+    uint32_t q[2], sp[2], nc[2], vp[2];
     bool on[2];
 #pragma unroll
     for (int h = 0; h < 2; h++) {
@@ -724,18 +727,24 @@ __global__ __launch_bounds__(256) void count_nt2_probe_kernel(DevIndex ix, const
       on[h] = lane + 64 * h < cnt;
       w[h] = on[h] ? s_vw[VERIFY ? wv_id : 0][s] : 0;
       q[h] = on[h] ? s_vq[VERIFY ? wv_id : 0][s] : 0;
-      vp[h] = on[h] ? s_vsp[VERIFY ? wv_id : 0][s] : 0;
-      if (!pos && on[h]) vp[h] = ix.dense_sa[vp[h]];
-      if (TALLY && on[h] && !pos) t_vsa++;
+      sp[h] = on[h] ? s_vsp[VERIFY ? wv_id : 0][s] : 0;
+      nc[h] = on[h] ? s_vn[VERIFY ? wv_id : 0][s] : 0;
+      vp[h] = sp[h];  // position seed: the entry is the candidate's text position already
+      if (on[h] && !(pos && nc[h] == 1u)) { vp[h] = ix.dense_sa[sp[h]]; if (TALLY) t_vsa++; }
     }
 #pragma unroll
     for (int h = 0; h < 2; h++) {
+      if (!on[h]) continue;
       uint64_t value = 0;
-      if (on[h] && vp[h] >= (uint32_t)i0) {  // else the suffix starts too close to the text's beginning
-        if (TALLY) t_vtxt++;
-        value = verify_part(ix.text4, (uint64_t)vp[h] - (uint64_t)i0, i0, 0, 0, w[h]) ? 0ull : 1ull;
+      for (uint32_t c = 0; c < nc[h]; c++) {  // the rows of a range are neighbours in the dense SA: mostly one line
+        const uint32_t p = c ? ix.dense_sa[sp[h] + c] : vp[h];
+        if (TALLY && c) t_vsa++;
+        if (p >= (uint32_t)i0) {  // else the suffix starts too close to the text's beginning
+          if (TALLY) t_vtxt++;
+          value += verify_part(ix.text4, (uint64_t)p - (uint64_t)i0, i0, 0, 0, w[h]) ? 0ull : 1ull;
+        }
       }
-      if (on[h]) counts[q[h]] = value;
+      counts[q[h]] = value;
     }
   };
   // the trip count is wave-uniform (ballots and the wave-level atomic below need every lane of the wave)
@@ -769,6 +778,8 @@ __global__ __launch_bounds__(256) void count_nt2_probe_kernel(DevIndex ix, const
           const uint32_t nc = (uint32_t)(w >> (2 * (i0 - 1))) & 3u;
           survivor = seed_sym(e) == (int)(nc == 3u ? 5u : nc + 1u);  // else BWT[sp] is not the next letter: absent
           if (verify && survivor) { queued = true; survivor = false; }
+        } else if (verify && cnt <= (uint32_t)VMULTI && (int)(3u * cnt) <= i0) {
+          queued = true;  // a handful of candidate rows: each is checked against the text here, none goes to phase 2
         } else survivor = true;
         if (!queued) counts[q] = value;  // coalesced; survivors are overwritten by phase 2
       }
@@ -780,6 +791,7 @@ __global__ __launch_bounds__(256) void count_nt2_probe_kernel(DevIndex ix, const
             s_vw[wv_id][s] = w;
             s_vsp[wv_id][s] = e.sp;
             s_vq[wv_id][s] = (uint32_t)q;
+            s_vn[wv_id][s] = (uint8_t)cnt;
           }
           vcount += (int)__popcll(qm);
           __builtin_amdgcn_wave_barrier();
@@ -1357,6 +1369,7 @@ __global__ __launch_bounds__(256) void count_nt2_reads_probe_kernel(DevIndex ix,
   constexpr int VQ = 192;
   __shared__ unsigned int s_count;
   __shared__ uint32_t s_vsp[4][VQ], s_vq[4][VQ];
+  __shared__ uint8_t s_vn[4][VQ];
   if (threadIdx.x == 0) s_count = 0;
   __syncthreads();
   const int lane = threadIdx.x & 63, wv_id = threadIdx.x >> 6;
@@ -1374,7 +1387,7 @@ __global__ __launch_bounds__(256) void count_nt2_reads_probe_kernel(DevIndex ix,
     if (range_start) range_start[q] = rs;
   };
   auto drain = [&](int base, int cnt) {  // queue entries [base, base + cnt), cnt <= 128: two per lane
-    uint32_t q[2], sp[2], vp[2];
+    uint32_t q[2], sp[2], nc[2], vp[2];
     bool on[2];
 #pragma unroll
     for (int h = 0; h < 2; h++) {
@@ -1382,18 +1395,25 @@ __global__ __launch_bounds__(256) void count_nt2_reads_probe_kernel(DevIndex ix,
       on[h] = lane + 64 * h < cnt;
       q[h] = on[h] ? s_vq[wv_id][s] : 0;
       sp[h] = on[h] ? s_vsp[wv_id][s] : 0;
-      vp[h] = on[h] ? (pos ? sp[h] : ix.dense_sa[sp[h]]) : 0;
+      nc[h] = on[h] ? s_vn[wv_id][s] : 0;
+      vp[h] = on[h] ? ((pos && nc[h] == 1u) ? sp[h] : ix.dense_sa[sp[h]]) : 0;
     }
 #pragma unroll
     for (int h = 0; h < 2; h++) {
       if (!on[h]) continue;
       const int i0 = (RAGGED ? (int)lens[q[h]] : L) - k, nchunks = (i0 + 31) >> 5;
-      uint32_t bad = vp[h] >= (uint32_t)i0 ? 0u : 1u;  // else the suffix starts too close to the text's beginning
-      const uint64_t g = (uint64_t)vp[h] - (uint64_t)i0;
       const uint64_t* qw = queries + (uint64_t)q[h] * W;
-      for (int c = 0; c < nchunks && !bad; c++) bad = verify_part(ix.text4, g, i0, c >> 2, c & 3, qw[c]);
-      if (!bad) settle(q[h], 1, (RS_SINGLE << RS_MODE_SHIFT) | g);
-      else settle(q[h], 0, (RS_MULTI << RS_MODE_SHIFT) | (uint64_t)sp[h] | ((uint64_t)i0 << 32));
+      uint32_t mask = 0;
+      uint64_t g1 = 0;
+      for (uint32_t c2 = 0; c2 < nc[h]; c2++) {  // the rows of a range are neighbours in the dense SA: mostly one line
+        const uint32_t p = c2 ? ix.dense_sa[sp[h] + c2] : vp[h];
+        uint32_t bad = p >= (uint32_t)i0 ? 0u : 1u;  // else the suffix starts too close to the text's beginning
+        const uint64_t g = (uint64_t)p - (uint64_t)i0;
+        for (int c = 0; c < nchunks && !bad; c++) bad = verify_part(ix.text4, g, i0, c >> 2, c & 3, qw[c]);
+        if (!bad) { mask |= 1u << c2; g1 = g; }
+      }
+      if (nc[h] == 1u && mask) settle(q[h], 1, (RS_SINGLE << RS_MODE_SHIFT) | g1);
+      else settle(q[h], (uint64_t)__popc(mask), (RS_MULTI << RS_MODE_SHIFT) | (uint64_t)sp[h] | ((uint64_t)i0 << 32) | ((uint64_t)mask << 48));
     }
   };
   constexpr int NQ = 2;  // reads in flight per lane
@@ -1439,7 +1459,9 @@ __global__ __launch_bounds__(256) void count_nt2_reads_probe_kernel(DevIndex ix,
         else if (cnt == 1u) {
           queued = seed_sym(e) == (int)(nc[h] == 3u ? 5u : nc[h] + 1u);
           if (!queued) settle(qv[h], 0, (RS_PLAIN << RS_MODE_SHIFT) | 1ull);  // BWT[sp] is not the next letter: absent
-        } else survivor = true;  // 2+ rows, or a saturated entry
+        } else if (cnt <= (uint32_t)VMULTI && (int)(3u * cnt) <= (RAGGED ? (int)lens[qv[h]] : L) - k) {
+          queued = true;  // a handful of candidate rows: each is checked against the text here
+        } else survivor = true;  // more rows, or a saturated entry
       }
       const uint64_t qm = __ballot(queued);
       if (qm) {
@@ -1447,6 +1469,7 @@ __global__ __launch_bounds__(256) void count_nt2_reads_probe_kernel(DevIndex ix,
           const int s = vcount + (int)__popcll(qm & lane_lt);
           s_vsp[wv_id][s] = e.sp;
           s_vq[wv_id][s] = (uint32_t)qv[h];
+          s_vn[wv_id][s] = (uint8_t)cnt;
         }
         vcount += (int)__popcll(qm);
         __builtin_amdgcn_wave_barrier();

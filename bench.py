@@ -460,6 +460,43 @@ def main():
             torch.cuda.empty_cache()
             result["locate"] = locate_benchmark(ix, text, torch, dev, stream, args.locate_reads, 101, oi, cores)
 
+    if world > 1:
+        # parity re-checked at every G.  All ranks count one common batch (half k-mers of the text, half
+        # random; same seeds everywhere): the replicas must agree among themselves (checksums reduced with MIN / MAX), and
+        # rank 0's answers must be the oracle's.  Outside the timed region.
+        from tests import synth
+        npar = 1_000_000
+        common = np.concatenate([synth.sampled_queries(text, npar // 2, L, 4711), synth.random_queries(npar // 2, L, 0, 4712)])
+        d_ascii = torch.from_numpy(common.reshape(-1)).to(dev)
+        d_w = torch.zeros(npar, dtype=torch.int64, device=dev)
+        d_b = torch.zeros(1, dtype=torch.int64, device=dev)
+        d_c = torch.zeros(npar, dtype=torch.int64, device=dev)
+        ix.dev_pack_nt2(d_ascii.data_ptr(), npar, L, d_w.data_ptr(), d_b.data_ptr(), stream, 0)
+        ix.dev_count_nt2(d_w.data_ptr(), npar, L, d_c.data_ptr(), True, stream, 0)
+        torch.cuda.synchronize()
+        weights = torch.arange(1, npar + 1, dtype=torch.int64, device=dev) % 1000003
+        chk = torch.stack([d_c.sum(), (d_c * weights).sum()])
+        if backend != "nccl":
+            chk = chk.cpu()
+        lo_, hi_ = chk.clone(), chk.clone()
+        dist.all_reduce(lo_, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi_, op=dist.ReduceOp.MAX)
+        agree = bool(torch.equal(lo_, hi_)) and int(d_b.item()) == 0
+        if rank == 0:
+            from oracle import oracle_ffi
+            path = "/tmp/awry_bench_%d.awry" % os.getpid()
+            ix.save(path)
+            oi = oracle_ffi.OracleIndex.load(path)
+            os.remove(path)
+            ocounts, _ = oi.parallel_count(*synth.fixed_to_csr(common), effective_cpus())
+            match = bool(np.array_equal(d_c.cpu().numpy().view(np.uint64), ocounts))
+            result["parity_check"] = {"queries": npar, "present_fraction": 0.5, "replicas_agree": agree, "rank0_matches_oracle": match}
+            if not (agree and match):
+                log("PARITY FAILURE at %d GPUs" % world)
+                print(json.dumps(result), flush=True)
+                dist.destroy_process_group()
+                sys.exit(3)
+
     if rank == 0:
         print(json.dumps(result), flush=True)
     if world > 1:

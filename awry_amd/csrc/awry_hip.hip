@@ -152,6 +152,7 @@ struct Replica {
   DevBuf<SeedEntry> seed;
   DevBuf<unsigned long long> chunk_counters;  // ring of work-queue heads, one per in-flight count / locate launch
   DevBuf<uint32_t> text4;                     // 4-bit text for seed-and-verify (device-only accelerator)
+  DevBuf<uint8_t> text8;                      // the text as symbol indices, for the generic kernel's verify (any alphabet)
   DevBuf<uint32_t> dense_sa;                  // SA[j * dense_ratio] as u32 (device-only accelerator for locate)
   DevBuf<uint32_t> sa_nblock;                 // SA of the rows whose suffix starts with N (kept while locate has to walk)
   uint32_t dense_ratio = 0;                   // 0 = use the file's bit-packed samples
@@ -172,7 +173,7 @@ struct Replica {
       if (ev0) (void)hipEventDestroy(ev0);
       if (ev1) (void)hipEventDestroy(ev1);
       blocks.reset(); sa_words.reset(); seq_starts.reset(); seed.reset(); chunk_counters.reset(); dense_sa.reset(); text4.reset();
-      sa_nblock.reset();
+      sa_nblock.reset(); text8.reset();
     }
   }
 };
@@ -363,6 +364,7 @@ std::unique_ptr<Replica> make_replica(awry_index* ix, int device) {
   d.seed_k = 0;
   d.dense_sa = nullptr;
   d.text4 = nullptr;
+  d.text8 = nullptr;
   d.dense_ratio = 0;
   d.verify_after = 0;
   d.sa_nblock = nullptr;
@@ -370,12 +372,11 @@ std::unique_ptr<Replica> make_replica(awry_index* ix, int device) {
   build_seed(ix, *r, ix->seed_k_request < 0 ? default_seed_k(h) : ix->seed_k_request);
   build_dense_sa(ix, *r, ix->dense_ratio_request);
   int vreq = ix->verify_request;
-  if (vreq == -2) {  // policy: keep the accelerators (5 B per text symbol) resident when they fit comfortably
+  if (vreq == -2) {  // policy: keep the accelerators (dense SA 4 B + text 1.5 B / 1 B per symbol) resident when they fit comfortably
     vreq = -1;
     const char* e = getenv("AWRY_VERIFY");
     size_t free_b = 0, total_b = 0;
-    if (!(e && !strcmp(e, "0")) && h.alphabet == NUCLEOTIDE && narrow(h) && hipMemGetInfo(&free_b, &total_b) == hipSuccess &&
-        (double)h.bwt_len * 6.0 < 0.5 * (double)free_b)
+    if (!(e && !strcmp(e, "0")) && narrow(h) && hipMemGetInfo(&free_b, &total_b) == hipSuccess && (double)h.bwt_len * 7.0 < 0.5 * (double)free_b)
       vreq = e && atoi(e) > 0 ? atoi(e) : 2;
   }
   if (vreq >= 0) build_verify(ix, *r, vreq);
@@ -398,14 +399,15 @@ void launch_pack_nt2(Replica& r, const uint8_t* d_ascii, const uint64_t* d_off, 
   HIP_CHECK(hipGetLastError());
 }
 
+// allow_verify: the generic kernel may finish queries against the text (ranges then hold RS_* words for locate, not rows)
 void launch_count_ascii(Replica& r, const uint8_t* d_q, const uint64_t* d_off, uint64_t n, uint64_t* d_counts,
-                        uint64_t* d_ranges, uint8_t* d_status, hipStream_t s) {
+                        uint64_t* d_ranges, uint8_t* d_status, hipStream_t s, bool allow_verify) {
   if (n == 0) return;
   const dim3 g(grid_for(r, n, 256)), b(256);
   if (r.dev.alphabet == NUCLEOTIDE)
-    hipLaunchKernelGGL(count_scalar_kernel<NUCLEOTIDE>, g, b, 0, s, r.dev, d_q, d_off, n, d_counts, d_ranges, d_status);
+    hipLaunchKernelGGL(count_scalar_kernel<NUCLEOTIDE>, g, b, 0, s, r.dev, d_q, d_off, n, d_counts, d_ranges, d_status, allow_verify ? 1 : 0);
   else
-    hipLaunchKernelGGL(count_scalar_kernel<AMINO>, g, b, 0, s, r.dev, d_q, d_off, n, d_counts, d_ranges, d_status);
+    hipLaunchKernelGGL(count_scalar_kernel<AMINO>, g, b, 0, s, r.dev, d_q, d_off, n, d_counts, d_ranges, d_status, allow_verify ? 1 : 0);
   HIP_CHECK(hipGetLastError());
 }
 
@@ -467,7 +469,9 @@ void launch_locate(Replica& r, const uint64_t* d_range_start, int rs_stride, con
 // dense device SA for locate: ratio 0 = off (walk to the file's samples), r >= 1 = keep SA[j r] for every j as u32
 void build_dense_sa(awry_index* ix, Replica& r, int ratio) {
   r.text4.reset();  // the verify shortcut rides on the ratio-1 dense SA; it is re-enabled by build_verify()
+  r.text8.reset();
   r.dev.text4 = nullptr;
+  r.dev.text8 = nullptr;
   r.dense_sa.reset();
   r.dense_ratio = 0;
   r.dev.dense_sa = nullptr;
@@ -510,24 +514,38 @@ void refresh_nblock(awry_index* ix, Replica& r) {
   r.dev.sa_nblock = r.sa_nblock.p;
 }
 
-// seed-and-verify for packed nucleotide reads: needs the ratio-1 dense SA and the 4-bit text, both recovered from the
-// index on the device.  after_steps < 0 switches it off.
+// seed-and-verify: needs the ratio-1 dense SA and the text, both recovered from the index on the device -- as 4-bit
+// codes for the packed nucleotide kernels (text4) and as one symbol index per byte for the generic kernel (text8, any
+// alphabet).  after_steps < 0 switches it off.
 void build_verify(awry_index* ix, Replica& r, int after_steps) {
   r.text4.reset();
+  r.text8.reset();
   r.dev.text4 = nullptr;
+  r.dev.text8 = nullptr;
   r.dev.verify_after = 0;
   if (after_steps < 0) return;
-  require(ix->host.alphabet == NUCLEOTIDE && narrow(ix->host), "seed-and-verify needs a nucleotide index with bwt_len < 2^32");
+  require(narrow(ix->host), "seed-and-verify needs an index with bwt_len < 2^32");
   if (r.dense_ratio != 1) build_dense_sa(ix, r, 1);
   if (r.dense_ratio != 1 || !r.dense_sa.p) throw HipError("seed-and-verify: the ratio-1 dense SA is missing");
-  const uint64_t nwords = (ix->host.bwt_len + 7) / 8 + 8;  // + slack: a 32-symbol window read touches 5 words
-  DevBuf<uint32_t> t(nwords);
-  HIP_CHECK(hipMemsetAsync(t.p, 0, nwords * 4, r.stream));
-  hipLaunchKernelGGL(text4_scatter_kernel<NUCLEOTIDE>, dim3(grid_for(r, ix->host.bwt_len, 256)), dim3(256), 0, r.stream, r.dev, t.p);
+  const bool nt = ix->host.alphabet == NUCLEOTIDE;
+  const dim3 g(grid_for(r, ix->host.bwt_len, 256)), b(256);
+  DevBuf<uint8_t> t8(ix->host.bwt_len + 16);
+  if (nt) hipLaunchKernelGGL(text8_scatter_kernel<NUCLEOTIDE>, g, b, 0, r.stream, r.dev, t8.p);
+  else hipLaunchKernelGGL(text8_scatter_kernel<AMINO>, g, b, 0, r.stream, r.dev, t8.p);
   HIP_CHECK(hipGetLastError());
+  if (nt) {
+    const uint64_t nwords = (ix->host.bwt_len + 7) / 8 + 8;  // + slack: a 32-symbol window read touches 5 words
+    DevBuf<uint32_t> t(nwords);
+    HIP_CHECK(hipMemsetAsync(t.p, 0, nwords * 4, r.stream));
+    hipLaunchKernelGGL(text4_scatter_kernel<NUCLEOTIDE>, g, b, 0, r.stream, r.dev, t.p);
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipStreamSynchronize(r.stream));
+    r.text4 = std::move(t);
+    r.dev.text4 = r.text4.p;
+  }
   HIP_CHECK(hipStreamSynchronize(r.stream));
-  r.text4 = std::move(t);
-  r.dev.text4 = r.text4.p;
+  r.text8 = std::move(t8);
+  r.dev.text8 = r.text8.p;
   r.dev.verify_after = (uint32_t)after_steps;
 }
 
@@ -696,7 +714,8 @@ struct ChunkBuffers {
 };
 
 // upload one chunk and run the generic count kernel; leaves counts / ranges / status on the device
-void run_count_chunk(Replica& r, ChunkBuffers& cb, const uint8_t* qbytes, const uint64_t* qoff, Shard c, bool want_ranges) {
+void run_count_chunk(Replica& r, ChunkBuffers& cb, const uint8_t* qbytes, const uint64_t* qoff, Shard c, bool want_ranges,
+                     bool allow_verify = true) {
   const uint64_t n = c.hi - c.lo, base = qoff[c.lo], nbytes = qoff[c.hi] - base;
   cb.h_off.resize(n + 1);
   for (uint64_t i = 0; i <= n; i++) {
@@ -710,7 +729,7 @@ void run_count_chunk(Replica& r, ChunkBuffers& cb, const uint8_t* qbytes, const 
   if (want_ranges && cb.ranges.n < 2 * n) cb.ranges.alloc(2 * n);
   if (nbytes) HIP_CHECK(hipMemcpyAsync(cb.q.p, qbytes + base, nbytes, hipMemcpyHostToDevice, r.stream));
   HIP_CHECK(hipMemcpyAsync(cb.off.p, cb.h_off.data(), (n + 1) * 8, hipMemcpyHostToDevice, r.stream));
-  launch_count_ascii(r, cb.q.p, cb.off.p, n, cb.counts.p, want_ranges ? cb.ranges.p : nullptr, cb.status.p, r.stream);
+  launch_count_ascii(r, cb.q.p, cb.off.p, n, cb.counts.p, want_ranges ? cb.ranges.p : nullptr, cb.status.p, r.stream, allow_verify);
   cb.h_status.resize(n);
   HIP_CHECK(hipMemcpyAsync(cb.h_status.data(), cb.status.p, n, hipMemcpyDeviceToHost, r.stream));
 }
@@ -1458,7 +1477,7 @@ int awry_search_range(awry_index_t* idx, const uint8_t* q, uint64_t len, awry_ra
     Replica& r = replica(idx, 0);
     ChunkBuffers cb;
     const uint64_t off[2] = {0, len};
-    run_count_chunk(r, cb, q, off, Shard{0, 1}, true);
+    run_count_chunk(r, cb, q, off, Shard{0, 1}, true, false);  // the caller wants rows
     uint64_t h[2];
     HIP_CHECK(hipMemcpyAsync(h, cb.ranges.p, 16, hipMemcpyDeviceToHost, r.stream));
     HIP_CHECK(hipStreamSynchronize(r.stream));
@@ -1648,7 +1667,9 @@ int awry_set_verify_kmers(awry_index_t* idx, int on) {
 const void* awry_debug_dense_sa(const awry_index_t* idx, int slot) {
   return idx && slot >= 0 && slot < (int)idx->reps.size() ? (const void*)idx->reps[slot]->dense_sa.p : nullptr;
 }
-int awry_verify_enabled(const awry_index_t* idx) { return idx && !idx->reps.empty() && idx->reps[0]->dev.text4 != nullptr; }
+int awry_verify_enabled(const awry_index_t* idx) {
+  return idx && !idx->reps.empty() && (idx->reps[0]->dev.text4 != nullptr || idx->reps[0]->dev.text8 != nullptr);
+}
 
 int awry_locate_sa_ratio(const awry_index_t* idx) {
   if (!idx || idx->reps.empty()) return 0;
@@ -1661,7 +1682,7 @@ int awry_dev_count_ascii(awry_index_t* idx, int slot, const void* d_qbytes, cons
     Replica& r = replica(idx, slot);
     require((d_qoff && d_counts) || n == 0, "null device pointer");
     launch_count_ascii(r, (const uint8_t*)d_qbytes, (const uint64_t*)d_qoff, n, (uint64_t*)d_counts, (uint64_t*)d_ranges,
-                       (uint8_t*)d_status, (hipStream_t)stream);
+                       (uint8_t*)d_status, (hipStream_t)stream, d_ranges == nullptr);  // ranges requested: they are row intervals
   });
 }
 

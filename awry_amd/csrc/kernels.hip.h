@@ -126,11 +126,14 @@ enum : uint8_t { Q_OK = 0, Q_EMPTY = 1, Q_SENTINEL = 2, Q_NON_ASCII = 3 };
 
 // status[q] != 0 marks inputs the reference leaves undefined: empty query, '$'/'#',
 // bytes >= 0x80.  ranges (optional) receives the final (start, end) row interval.
+// allow_verify (with the dense SA and ix.text8 resident): once the range has shrunk to <= 4 rows, the letters still to
+// the left are compared with the text in front of each candidate instead of being stepped one by one; ranges[2q] then
+// holds an RS_SINGLE / RS_MULTI word for the locate pass, not a row interval -- callers that need rows pass 0.
 template <int A>
 __global__ __launch_bounds__(256) void count_scalar_kernel(DevIndex ix, const uint8_t* __restrict__ ascii,
                                                            const uint64_t* __restrict__ off, uint64_t n,
                                                            uint64_t* __restrict__ counts, uint64_t* __restrict__ ranges,
-                                                           uint8_t* __restrict__ status) {
+                                                           uint8_t* __restrict__ status, int allow_verify) {
   __shared__ uint8_t lut[256];
   lut[threadIdx.x] = (uint8_t)(threadIdx.x >= 128 ? 0xFF : index_of_ascii(A, (uint8_t)threadIdx.x));
   __syncthreads();
@@ -143,7 +146,8 @@ __global__ __launch_bounds__(256) void count_scalar_kernel(DevIndex ix, const ui
       if (s == 0xFF) st = Q_NON_ASCII;
       else if (s == 0 && st == Q_OK) st = Q_SENTINEL;
     }
-    uint64_t sp = 1, ep = 0;
+    uint64_t sp = 1, ep = 0, vcount = 0, vrs = 0;
+    bool verified = false;
     if (st == Q_OK) {
       uint64_t i = e - 1;
       bool seeded = false;
@@ -182,8 +186,21 @@ __global__ __launch_bounds__(256) void count_scalar_kernel(DevIndex ix, const ui
           const uint32_t scnt = seed_cnt(se);
           const bool wrong_sym = scnt == 1 && e - k > b && seed_sym(se) != (int)lut[ascii[e - k - 1]];  // BWT[row] is not the next symbol
           // position seeds (ix.seed_pos): a singleton entry names a text position, not a row -- good enough to reject
-          // the query by its symbol, not to continue the search: such a query starts without the table
-          if (scnt != SEED_CNT_SAT && !(ix.seed_pos && scnt == 1 && !wrong_sym)) {
+          // the query by its symbol or to finish it against the text, not to continue the search: without the text
+          // such a query starts over without the table
+          if (ix.seed_pos && scnt == 1 && !wrong_sym) {
+            const uint64_t rem = e - k - b, p = se.sp;
+            if (allow_verify && ix.text8 && rem < 65536) {
+              bool same = p >= rem;  // else the suffix starts too close to the text's beginning
+              const uint8_t* t = ix.text8 + (p - rem);
+              for (uint64_t j = 0; j < rem && same; j++) same = t[j] == lut[ascii[b + j]];
+              verified = true;
+              vcount = same ? 1 : 0;
+              vrs = same ? ((RS_SINGLE << RS_MODE_SHIFT) | (p - rem)) : ((RS_MULTI << RS_MODE_SHIFT) | (rem << 32));
+              seeded = true;
+              sp = 1; ep = 0;  // skips the step loop below
+            }
+          } else if (scnt != SEED_CNT_SAT) {
             sp = scnt ? se.sp : 1;
             ep = scnt ? (uint64_t)se.sp + scnt - 1 : 0;
             i = e - k;
@@ -197,13 +214,37 @@ __global__ __launch_bounds__(256) void count_scalar_kernel(DevIndex ix, const ui
         sp = ix.prefix_sums[idx];          // SearchRange::new, src/search.rs:43-48
         ep = ix.prefix_sums[idx + 1] - 1;
       }
+      const bool can_verify = allow_verify && ix.text8 && ix.dense_sa && ix.dense_ratio == 1;
       while (i > b && sp <= ep) {        // emptiness is sticky, so stopping early never changes the count
+        const uint64_t rem = i - b, cnt = ep - sp + 1;
+        if (can_verify && cnt <= 4 && 3 * cnt <= rem && rem < 65536) {
+          uint32_t mask = 0;
+          uint64_t g1 = 0;
+          for (uint64_t c = 0; c < cnt; c++) {
+            const uint64_t p = ix.dense_sa[sp + c];
+            if (p < rem) continue;  // the suffix starts too close to the text's beginning
+            const uint8_t* t = ix.text8 + (p - rem);
+            bool same = true;
+            for (uint64_t j = 0; j < rem && same; j++) same = t[j] == lut[ascii[b + j]];
+            if (same) { mask |= 1u << c; g1 = p - rem; }
+          }
+          verified = true;
+          vcount = (uint64_t)__popc(mask);
+          vrs = (cnt == 1 && mask) ? ((RS_SINGLE << RS_MODE_SHIFT) | g1)
+                                   : ((RS_MULTI << RS_MODE_SHIFT) | sp | (rem << 32) | ((uint64_t)mask << 48));
+          break;
+        }
         i--;
         step_scalar<A>(ix, sp, ep, lut[ascii[i]]);
       }
     }
-    counts[q] = sp > ep ? 0 : ep - sp + 1;  // src/search.rs:66-71
-    if (ranges) { ranges[2 * q] = sp; ranges[2 * q + 1] = ep; }
+    if (verified) {
+      counts[q] = vcount;
+      if (ranges) { ranges[2 * q] = vrs; ranges[2 * q + 1] = 0; }
+    } else {
+      counts[q] = sp > ep ? 0 : ep - sp + 1;  // src/search.rs:66-71
+      if (ranges) { ranges[2 * q] = sp; ranges[2 * q + 1] = ep; }
+    }
     if (status) status[q] = st;
   }
 }
@@ -1571,6 +1612,16 @@ __global__ __launch_bounds__(256) void text4_scatter_kernel(DevIndex ix, uint32_
     const int letter = nt_letter_of_index(symbol_at<A>(ix, r));
     const uint32_t code = letter >= 0 ? (uint32_t)letter : 8u;
     if (code) atomicOr(&text4[p >> 3], code << (4 * (p & 7)));
+  }
+}
+
+// the text as symbol indices, one byte per position (DevIndex::text8), by the same identity
+template <int A>
+__global__ __launch_bounds__(256) void text8_scatter_kernel(DevIndex ix, uint8_t* __restrict__ text8) {
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < ix.bwt_len; r += stride) {
+    const uint64_t v = ix.dense_sa[r];
+    text8[v ? v - 1 : ix.bwt_len - 1] = (uint8_t)symbol_at<A>(ix, r);
   }
 }
 

@@ -92,6 +92,8 @@ struct DevIndex {
   const uint32_t* text4;      // the text as 4-bit codes (A0 C1 G2 T3, 8 = anything else), 8 symbols per u32, LSB first
   uint32_t dense_ratio;
   uint32_t verify_after;      // seed-and-verify: switch from LF steps to text comparison after this many steps
+  const uint8_t* text8;       // the text as symbol indices (0 = '$'), one byte per position: lets the generic kernel finish a
+                              //   query against the text like the packed kernels do, for any alphabet and any letters
   uint32_t seed_pos;          // 1: singleton seed entries hold the TEXT POSITION SA[row] in .sp instead of the row (kept only
                               //   while the verify accelerators are resident and the two-phase schedules are the policy)
   const uint32_t* sa_nblock;  // SA of every row whose suffix starts with N (rows [C[N], C[T])), or nullptr: ends locate

@@ -770,7 +770,9 @@ def test_default_device_policies():
     assert not ix.verify_enabled() and ix.locate_sa_ratio() == 8
     aa, st, hd = synth.make_text(50_000, 1, 4, 3)
     ax = gpu_index(aa, 1, 8, 0, st, hd)
-    assert ax.seed_kmer_len() == 4 and not ax.verify_enabled()   # floor(log20(5e4)) + 1
+    assert ax.seed_kmer_len() == 4 and ax.verify_enabled()       # floor(log20(5e4)) + 1; dense SA + byte text for the generic kernel
+    ax.set_verify(-1)
+    assert not ax.verify_enabled()
 
 
 def test_amino_seed_table_does_not_change_counts(oracle):

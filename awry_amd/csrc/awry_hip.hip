@@ -309,15 +309,20 @@ void refresh_nblock(awry_index* ix, Replica& r);
 void sync_seed_mode(awry_index* ix, Replica& r) {
   const HostIndex& h = ix->host;
   static const bool off = getenv("AWRY_SEED_POS") && !strcmp(getenv("AWRY_SEED_POS"), "0");
-  const bool want = !off && h.alphabet == NUCLEOTIDE && narrow(h) && r.seed_k > 0 && r.seed.p && r.dev.text4 && r.dense_ratio == 1 &&
-                    r.dense_sa.p && (1ull << (2 * r.seed_k)) / 3 >= h.bwt_len;
+  const bool nt = h.alphabet == NUCLEOTIDE;
+  // nucleotide: text4 resident and the two-phase schedules are the policy; amino: text8 resident (its only consumer, the
+  // generic kernel, then finishes singletons against the text)
+  const bool want = !off && narrow(h) && r.seed_k > 0 && r.seed.p && r.dense_ratio == 1 && r.dense_sa.p &&
+                    (nt ? (r.dev.text4 && (1ull << (2 * r.seed_k)) / 3 >= h.bwt_len) : r.dev.text8 != nullptr);
   if (want == (r.dev.seed_pos != 0)) return;
   if (!want) {  // rows again: rebuild (the row of a position is not recoverable without an inverse SA)
     build_seed(ix, r, r.seed_k);
     return;
   }
-  const uint64_t nfinal = 1ull << (2 * r.seed_k);
-  hipLaunchKernelGGL(seed_rows_to_positions_kernel, dim3(grid_for(r, nfinal, 256)), dim3(256), 0, r.stream, r.seed.p, nfinal, r.dense_sa.p);
+  uint64_t nfinal = 1;
+  for (int j = 0; j < r.seed_k; j++) nfinal *= nt ? 4 : 20;
+  hipLaunchKernelGGL(seed_rows_to_positions_kernel, dim3(grid_for(r, nfinal, 256)), dim3(256), 0, r.stream, r.seed.p, nfinal, r.dense_sa.p,
+                     nt ? SEED_CNT_SAT : AA_SEED_CNT_SAT);
   HIP_CHECK(hipGetLastError());
   HIP_CHECK(hipStreamSynchronize(r.stream));
   r.dev.seed_pos = 1;

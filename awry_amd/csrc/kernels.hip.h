@@ -163,12 +163,25 @@ __global__ __launch_bounds__(256) void count_scalar_kernel(DevIndex ix, const ui
         if (std20) {
           const SeedEntry se = ix.seed[sidx];
           const uint32_t scnt = se.cnt & AA_SEED_CNT_SAT;
-          if (scnt != AA_SEED_CNT_SAT) {
+          const bool wrong_sym = scnt == 1 && e - k > b && (int)(se.cnt >> 27) != (int)lut[ascii[e - k - 1]];  // BWT[row] is not the next residue
+          if (ix.seed_pos && scnt == 1 && !wrong_sym) {  // position seed, as in the nucleotide branch below
+            const uint64_t rem = e - k - b, p = se.sp;
+            if (allow_verify && ix.text8 && rem < 65536) {
+              bool same = p >= rem;
+              const uint8_t* t = ix.text8 + (p - rem);
+              for (uint64_t j = 0; j < rem && same; j++) same = t[j] == lut[ascii[b + j]];
+              verified = true;
+              vcount = same ? 1 : 0;
+              vrs = same ? ((RS_SINGLE << RS_MODE_SHIFT) | (p - rem)) : ((RS_MULTI << RS_MODE_SHIFT) | (rem << 32));
+              seeded = true;
+              sp = 1; ep = 0;
+            }
+          } else if (scnt != AA_SEED_CNT_SAT) {
             sp = scnt ? se.sp : 1;
             ep = scnt ? (uint64_t)se.sp + scnt - 1 : 0;
             i = e - k;
             seeded = true;
-            if (scnt == 1 && i > b && (int)(se.cnt >> 27) != (int)lut[ascii[i - 1]]) { sp = 1; ep = 0; }  // BWT[sp] is not the next residue
+            if (wrong_sym) { sp = 1; ep = 0; }
           }
         }
       }
@@ -1108,11 +1121,11 @@ __global__ __launch_bounds__(256) void seed_finalize_kernel(DevIndex ix, SeedEnt
 // suffix.  A query whose seed window occurs once in the text then needs no SA read: the entry itself says where the
 // single candidate is, and the text decides (2 random lines per such query instead of 3).
 __global__ __launch_bounds__(256) void seed_rows_to_positions_kernel(SeedEntry* __restrict__ table, uint64_t nentries,
-                                                                     const uint32_t* __restrict__ dense_sa) {
+                                                                     const uint32_t* __restrict__ dense_sa, uint32_t cnt_mask) {
   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
   for (uint64_t o = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; o < nentries; o += stride) {
     const SeedEntry e = table[o];
-    if (seed_cnt(e) == 1u) table[o].sp = dense_sa[e.sp];
+    if ((e.cnt & cnt_mask) == 1u) table[o].sp = dense_sa[e.sp];  // cnt_mask: SEED_CNT_SAT (nt) / AA_SEED_CNT_SAT (aa)
   }
 }
 

@@ -161,6 +161,18 @@ def test_query_file_ingestion(tmp_path):
     with pytest.raises(AwryError) as e:
         read_query_file(str(tmp_path / "missing.fq"))
     assert e.value.code == ERR_IO
+    # odd but legal inputs: empty file, no newline at the end, CRLF, blank lines between records, header without sequence
+    (tmp_path / "empty.fa").write_bytes(b"")
+    qb, qo = read_query_file(str(tmp_path / "empty.fa"))
+    assert qo.tolist() == [0] and len(qb) == 0
+    (tmp_path / "tail.fq").write_bytes(b"@a\r\nAC\r\n+\r\nII\r\n\r\n@b\nGGT\n+\nIII")
+    qb, qo = read_query_file(str(tmp_path / "tail.fq"))
+    assert qo.tolist() == [0, 2, 5] and bytes(qb) == b"ACGGT"
+    (tmp_path / "hdr.fa").write_bytes(b"ACG\n>x\n>y\nTT")
+    qb, qo = read_query_file(str(tmp_path / "hdr.fa"))
+    assert qo.tolist() == [0, 3, 3, 5] and bytes(qb) == b"ACGTT"
+    with pytest.raises(AwryError):
+        FmIndex.new(FmBuildArgs(str(tmp_path / "empty.fa")))
 
 
 def test_query_file_ingestion_parallel_chunks(tmp_path):

@@ -727,7 +727,7 @@ void run_count_chunk(Replica& r, ChunkBuffers& cb, const uint8_t* qbytes, const 
     if (qoff[c.lo + i] < base || (i && qoff[c.lo + i] < qoff[c.lo + i - 1])) throw ArgError("query offsets must be non-decreasing");
     cb.h_off[i] = qoff[c.lo + i] - base;
   }
-  if (cb.q.n < nbytes + 1) cb.q.alloc(nbytes + 1);
+  if (cb.q.n < nbytes + 16) cb.q.alloc(nbytes + 16);  // the kernel reads whole aligned 8-byte words
   if (cb.off.n < n + 1) cb.off.alloc(n + 1);
   if (cb.counts.n < n) cb.counts.alloc(n);
   if (cb.status.n < n) cb.status.alloc(n);

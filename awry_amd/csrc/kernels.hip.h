@@ -124,6 +124,22 @@ __device__ __forceinline__ uint64_t sa_sample(const DevIndex& ix, uint64_t sampl
 
 enum : uint8_t { Q_OK = 0, Q_EMPTY = 1, Q_SENTINEL = 2, Q_NON_ASCII = 3 };
 
+// Byte access through aligned 8-byte loads: one memory instruction per 8 consecutive bytes instead of one per byte
+// (the lanes of a wave read different queries, so every byte load is a line lookup of its own in the texture path;
+// the generic kernel's loops were bound by exactly that).  Reads the aligned word around a byte: the buffer must be
+// readable up to the next 8-byte boundary (device allocations are).
+struct ByteStream {
+  const uint8_t* base;
+  uint64_t word = 0;
+  uintptr_t at = ~(uintptr_t)0;
+  __device__ __forceinline__ explicit ByteStream(const uint8_t* p) : base(p) {}
+  __device__ __forceinline__ uint8_t operator[](uint64_t i) {
+    const uintptr_t a = reinterpret_cast<uintptr_t>(base + i), w = a & ~(uintptr_t)7;
+    if (w != at) { word = *reinterpret_cast<const uint64_t*>(w); at = w; }
+    return (uint8_t)(word >> (8 * (a & 7)));
+  }
+};
+
 // status[q] != 0 marks inputs the reference leaves undefined: empty query, '$'/'#',
 // bytes >= 0x80.  ranges (optional) receives the final (start, end) row interval.
 // allow_verify (with the dense SA and ix.text8 resident): once the range has shrunk to <= 4 rows, the letters still to
@@ -138,8 +154,10 @@ __global__ __launch_bounds__(256) void count_scalar_kernel(DevIndex ix, const ui
   lut[threadIdx.x] = (uint8_t)(threadIdx.x >= 128 ? 0xFF : index_of_ascii(A, (uint8_t)threadIdx.x));
   __syncthreads();
   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  const uint8_t* const ascii_bytes = ascii;
   for (uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += stride) {
     const uint64_t b = off[q], e = off[q + 1];
+    ByteStream ascii(ascii_bytes);  // shadows the pointer: same indexing, 8 bytes per load
     uint8_t st = e > b ? Q_OK : Q_EMPTY;
     for (uint64_t i = b; i < e; i++) {
       uint8_t s = lut[ascii[i]];
@@ -168,7 +186,7 @@ __global__ __launch_bounds__(256) void count_scalar_kernel(DevIndex ix, const ui
             const uint64_t rem = e - k - b, p = se.sp;
             if (allow_verify && ix.text8 && rem < 65536) {
               bool same = p >= rem;
-              const uint8_t* t = ix.text8 + (p - rem);
+              ByteStream t(ix.text8 + (p - rem));
               for (uint64_t j = 0; j < rem && same; j++) same = t[j] == lut[ascii[b + j]];
               verified = true;
               vcount = same ? 1 : 0;
@@ -205,7 +223,7 @@ __global__ __launch_bounds__(256) void count_scalar_kernel(DevIndex ix, const ui
             const uint64_t rem = e - k - b, p = se.sp;
             if (allow_verify && ix.text8 && rem < 65536) {
               bool same = p >= rem;  // else the suffix starts too close to the text's beginning
-              const uint8_t* t = ix.text8 + (p - rem);
+              ByteStream t(ix.text8 + (p - rem));
               for (uint64_t j = 0; j < rem && same; j++) same = t[j] == lut[ascii[b + j]];
               verified = true;
               vcount = same ? 1 : 0;
@@ -236,7 +254,7 @@ __global__ __launch_bounds__(256) void count_scalar_kernel(DevIndex ix, const ui
           for (uint64_t c = 0; c < cnt; c++) {
             const uint64_t p = ix.dense_sa[sp + c];
             if (p < rem) continue;  // the suffix starts too close to the text's beginning
-            const uint8_t* t = ix.text8 + (p - rem);
+            ByteStream t(ix.text8 + (p - rem));
             bool same = true;
             for (uint64_t j = 0; j < rem && same; j++) same = t[j] == lut[ascii[b + j]];
             if (same) { mask |= 1u << c; g1 = p - rem; }

@@ -322,7 +322,7 @@ void sync_seed_mode(awry_index* ix, Replica& r) {
   uint64_t nfinal = 1;
   for (int j = 0; j < r.seed_k; j++) nfinal *= nt ? 4 : 20;
   hipLaunchKernelGGL(seed_rows_to_positions_kernel, dim3(grid_for(r, nfinal, 256)), dim3(256), 0, r.stream, r.seed.p, nfinal, r.dense_sa.p,
-                     nt ? SEED_CNT_SAT : AA_SEED_CNT_SAT);
+                     nt ? SEED_CNT_SAT : AA_SEED_CNT_SAT, nt ? r.dev.text4 : nullptr);
   HIP_CHECK(hipGetLastError());
   HIP_CHECK(hipStreamSynchronize(r.stream));
   r.dev.seed_pos = 1;

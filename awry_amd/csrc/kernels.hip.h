@@ -846,7 +846,10 @@ __global__ __launch_bounds__(256) void count_nt2_probe_kernel(DevIndex ix, const
         if (cnt == SEED_CNT_SAT) survivor = true;
         else if (cnt == 0u) value = 0;
         else if (i0 == 0) value = cnt;
-        else if (cnt == 1u) {
+        else if (cnt == 1u && pos && seed_has_ctx(e) && i0 <= SEED_CTX_LEN) {
+          // the entry holds the letters in front of the one occurrence: decided here, no text access
+          value = (w & ((1ull << (2 * i0)) - 1)) == (uint64_t)(seed_ctx(e) >> (2 * (SEED_CTX_LEN - i0))) ? 1ull : 0ull;
+        } else if (cnt == 1u) {
           const uint32_t nc = (uint32_t)(w >> (2 * (i0 - 1))) & 3u;
           survivor = seed_sym(e) == (int)(nc == 3u ? 5u : nc + 1u);  // else BWT[sp] is not the next letter: absent
           if (verify && survivor) { queued = true; survivor = false; }
@@ -1138,12 +1141,33 @@ __global__ __launch_bounds__(256) void seed_finalize_kernel(DevIndex ix, SeedEnt
 // Position seeds (DevIndex::seed_pos): every singleton entry's row is replaced by the text position of that row's
 // suffix.  A query whose seed window occurs once in the text then needs no SA read: the entry itself says where the
 // single candidate is, and the text decides (2 random lines per such query instead of 3).
+// text4 != nullptr (nucleotide): where the SEED_CTX_LEN letters in front of the occurrence exist and are all ACGT they
+// go into the entry as well (SEED_CTX, layout.h).
 __global__ __launch_bounds__(256) void seed_rows_to_positions_kernel(SeedEntry* __restrict__ table, uint64_t nentries,
-                                                                     const uint32_t* __restrict__ dense_sa, uint32_t cnt_mask) {
+                                                                     const uint32_t* __restrict__ dense_sa, uint32_t cnt_mask,
+                                                                     const uint32_t* __restrict__ text4) {
   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
   for (uint64_t o = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; o < nentries; o += stride) {
-    const SeedEntry e = table[o];
-    if ((e.cnt & cnt_mask) == 1u) table[o].sp = dense_sa[e.sp];  // cnt_mask: SEED_CNT_SAT (nt) / AA_SEED_CNT_SAT (aa)
+    SeedEntry e = table[o];
+    if ((e.cnt & cnt_mask) != 1u) continue;  // cnt_mask: SEED_CNT_SAT (nt) / AA_SEED_CNT_SAT (aa)
+    const uint32_t p = dense_sa[e.sp];
+    e.sp = p;
+    if (text4 && p >= (uint32_t)SEED_CTX_LEN) {
+      const uint64_t t0 = (uint64_t)p - SEED_CTX_LEN;  // 14 nibbles from nibble t0: at most three words
+      const uint32_t* wp = text4 + (t0 >> 3);
+      const int sh = 4 * (int)(t0 & 7);
+      const uint64_t a0 = (uint64_t)wp[0] | ((uint64_t)wp[1] << 32), a1 = wp[2];
+      uint64_t x = (sh ? (a0 >> sh) | (a1 << (64 - sh)) : a0) & 0x00FFFFFFFFFFFFFFull;
+      if ((x & 0x0088888888888888ull) == 0) {  // all fourteen are A, C, G or T: nibbles -> 2-bit letters
+        x &= 0x3333333333333333ull;
+        x = (x | (x >> 2)) & 0x0F0F0F0F0F0F0F0Full;
+        x = (x | (x >> 4)) & 0x00FF00FF00FF00FFull;
+        x = (x | (x >> 8)) & 0x0000FFFF0000FFFFull;
+        x = (x | (x >> 16)) & 0x00000000FFFFFFFFull;
+        e.cnt = (e.cnt & 0xE0000000u) | SEED_CTX | (uint32_t)x;
+      }
+    }
+    table[o] = e;
   }
 }
 
@@ -1528,7 +1552,22 @@ __global__ __launch_bounds__(256) void count_nt2_reads_probe_kernel(DevIndex ix,
         survivor = true;
       } else if (valid) {
         if (cnt == 0u) settle(qv[h], 0, (RS_PLAIN << RS_MODE_SHIFT) | 1ull);
-        else if (cnt == 1u) {
+        else if (cnt == 1u && pos && seed_has_ctx(e)) {
+          // the entry holds the 14 letters in front of the one occurrence: a read with no more than that left of its
+          // seed window is decided here; a longer one goes on to the text only if those 14 agree
+          const int i0 = (RAGGED ? (int)lens[qv[h]] : L) - k;
+          const uint64_t* qw = queries + qv[h] * W;
+          if (i0 <= SEED_CTX_LEN) {
+            const bool same = (qw[0] & ((1ull << (2 * i0)) - 1)) == (uint64_t)(seed_ctx(e) >> (2 * (SEED_CTX_LEN - i0)));
+            settle(qv[h], same ? 1 : 0, same ? ((RS_SINGLE << RS_MODE_SHIFT) | (uint64_t)(e.sp - (uint32_t)i0)) : ((RS_PLAIN << RS_MODE_SHIFT) | 1ull));
+          } else {
+            const int f = i0 - SEED_CTX_LEN, a = f >> 5, sh = 2 * (f & 31);
+            uint64_t x = qw[a] >> sh;
+            if (sh && a + 1 < W) x |= qw[a + 1] << (64 - sh);
+            queued = (x & ((1ull << (2 * SEED_CTX_LEN)) - 1)) == (uint64_t)seed_ctx(e);
+            if (!queued) settle(qv[h], 0, (RS_PLAIN << RS_MODE_SHIFT) | 1ull);
+          }
+        } else if (cnt == 1u) {
           queued = seed_sym(e) == (int)(nc[h] == 3u ? 5u : nc[h] + 1u);
           if (!queued) settle(qv[h], 0, (RS_PLAIN << RS_MODE_SHIFT) | 1ull);  // BWT[sp] is not the next letter: absent
         } else if (cnt <= (uint32_t)VMULTI && (int)(3u * cnt) <= (RAGGED ? (int)lens[qv[h]] : L) - k) {

@@ -63,13 +63,21 @@ AWRY_HD int nt_letter_of_index(int idx) { return idx == 5 ? 3 : (idx >= 1 && idx
 AWRY_HD int nt_index_of_letter(int l) { return l == 3 ? 5 : l + 1; }
 
 // seed-table entry: the search range of a k-mer as (start row, row count); count 0 = absent.
-// Final-level entries pack two things into `cnt`: bits 0..28 the count, saturating at SEED_CNT_SAT ("at least
+// Final-level nucleotide entries pack more into `cnt`: bits 0..27 the count, saturating at SEED_CNT_SAT ("at least
 // this many: ignore the table for this query"), and -- for singleton ranges only -- bits 29..31 the symbol index
 // stored in the BWT at row sp.  A singleton range survives a step with symbol c iff BWT[sp] == c, so most absent
 // k-mers are rejected by the entry itself, without touching a BWT block.
+// With position seeds (DevIndex::seed_pos) a singleton's sp is the text position p of its one occurrence, and bit 28
+// (SEED_CTX) says that bits 0..27 hold the SEED_CTX_LEN = 14 letters in front of it instead of the count 1:
+// text[p - 14 + j] in bits [2j, 2j + 2) -- the orientation of a packed query word -- so that a 31-mer probed with
+// k = 17 is decided by its entry alone.  Set only where those 14 positions exist and are all ACGT.
 struct SeedEntry { uint32_t sp, cnt; };
-constexpr uint32_t SEED_CNT_SAT = 0x1FFFFFFFu;
-AWRY_HD uint32_t seed_cnt(SeedEntry e) { return e.cnt & SEED_CNT_SAT; }
+constexpr uint32_t SEED_CNT_SAT = 0x0FFFFFFFu;
+constexpr uint32_t SEED_CTX = 0x10000000u;
+constexpr int SEED_CTX_LEN = 14;
+AWRY_HD bool seed_has_ctx(SeedEntry e) { return (e.cnt & SEED_CTX) != 0; }
+AWRY_HD uint32_t seed_cnt(SeedEntry e) { return seed_has_ctx(e) ? 1u : (e.cnt & SEED_CNT_SAT); }
+AWRY_HD uint32_t seed_ctx(SeedEntry e) { return e.cnt & SEED_CNT_SAT; }
 AWRY_HD int seed_sym(SeedEntry e) { return (int)(e.cnt >> 29); }
 
 // amino seed entries: count in bits 0..26 (saturating), 5-bit symbol index of a singleton's BWT row in bits 27..31

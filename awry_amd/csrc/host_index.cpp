@@ -192,6 +192,7 @@ inline size_t count_nonspace(const char* q, size_t n) {
   return k;
 }
 inline uint8_t* copy_nonspace(uint8_t* dst, const char* q, size_t n, bool upper) {
+  if (n == 0) return dst;
   if (!has_space(q, n)) {
     if (!upper) { memcpy(dst, q, n); return dst + n; }
     for (size_t i = 0; i < n; i++) {  // ASCII upper-casing, vectorisable

@@ -64,10 +64,38 @@ int main(int argc, char** argv) {
         c2 = nh; orc_free(g); orc_free(p);
         if (c1 != c2) { printf("count/locate mismatch\n"); return 1; }
       }
-      std::vector<uint8_t> qb; std::vector<uint64_t> qo;
-      read_query_file(fa, qb, qo);
+      uint8_t* qb = nullptr; uint64_t* qo = nullptr; uint64_t nq = 0;
+      read_query_file(fa, &qb, &qo, &nq);
+      if (nq != sf.starts.size() || qo[nq] + nq != sf.text.size()) { printf("query reader disagrees with the sequence reader\n"); return 1; }
+      free(qb); free(qo);
       orc_index_free(oi); orc_index_free(o2);
     }
+  }
+  {  // files big enough for the chunked, multi-threaded readers (FASTQ and wrapped FASTA)
+    std::string fq = std::string(argv[1]) + "/big.fq", fa = std::string(argv[1]) + "/big.fa";
+    FILE* f = fopen(fq.c_str(), "w");
+    FILE* g = fopen(fa.c_str(), "w");
+    size_t total = 0, nrec = 0;
+    while (total < (12u << 20)) {
+      size_t len = rng() % 400;
+      std::string s, ql;
+      for (size_t i = 0; i < len; i++) { s.push_back("ACGTN"[rng() % 5]); ql.push_back((char)(33 + rng() % 60)); }
+      if (len && nrec % 3 == 0) ql[0] = '@';
+      fprintf(f, "@r%zu\n%s\n+\n%s\n", nrec, s.c_str(), ql.c_str());
+      fprintf(g, ">r%zu\n", nrec);
+      for (size_t i = 0; i < len; i += 61) fprintf(g, "%s\n", s.substr(i, 61).c_str());
+      total += 2 * len + 16;
+      nrec++;
+    }
+    fclose(f);
+    fclose(g);
+    uint8_t *b1 = nullptr, *b2 = nullptr; uint64_t *o1 = nullptr, *o2 = nullptr, n1 = 0, n2 = 0;
+    read_query_file(fq, &b1, &o1, &n1);
+    read_query_file(fa, &b2, &o2, &n2);
+    if (n1 != nrec || n2 != nrec || o1[n1] != o2[n2] || memcmp(b1, b2, o1[n1]) || memcmp(o1, o2, (n1 + 1) * 8)) { printf("big reader mismatch\n"); return 1; }
+    SequenceFile sf = read_sequence_file(fa, 0);
+    if (sf.starts.size() != nrec || sf.text.size() != o1[n1] + nrec) { printf("big sequence reader mismatch\n"); return 1; }
+    free(b1); free(b2); free(o1); free(o2);
   }
   puts("asan-host-check-ok");
   return 0;

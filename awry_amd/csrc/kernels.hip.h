@@ -15,15 +15,22 @@
 //     64-symbol slice with __popcll and sums partials with two quad_perm DPP adds -- no LDS round trip.
 //
 // Kernel map (default in CAPS; the others are kept as measured alternatives):
-//   count, any query      count_scalar_kernel<A>         ASCII + offsets, one query per lane, seed probe when possible
-//   count, packed k-mers  COUNT_NT2_QUAD4_KERNEL         groups of four queries per quad, grouped seed probes
-//                         count_nt2_quad_kernel          one strided query per quad
-//                         count_nt2_chunk_kernel         queries/results staged through LDS per wave
-//   count, packed reads   COUNT_NT2_READS_KERNEL         any length, multi-word; optional seed-and-verify
-//   locate                LOCATE_TILE_KERNEL<A>          tiles of hits, per-lane walk state machines, dense SA
-//                         locate_scalar_kernel<A>        one hit per lane (round-1 baseline)
-//   accelerators          seed_level1/extend/finalize, densify_sa_kernel, text4_scatter_kernel
-//   glue                  pack_nt2_tile_kernel, scan_*_kernel, ref_kmer_table_kernel, scalar_ops_kernel
+//   count, any query      COUNT_SCALAR_KERNEL<A>             ASCII + offsets, one query per lane, seed probe, verify against text8
+//   count, packed k-mers  COUNT_NT2_PROBE_KERNEL             phase 1: one query per lane, entry / context / text decide most
+//                         + COUNT_NT2_RESUME_KERNEL          phase 2: quads resume the listed survivors (sparse seed tables)
+//                         COUNT_NT2_QUAD4_KERNEL             groups of four queries per quad (dense seed tables)
+//                         count_nt2_quad_kernel              one strided query per quad
+//                         count_nt2_chunk_kernel             queries/results staged through LDS per wave
+//   count, packed reads   COUNT_NT2_READS_PROBE_KERNEL<R>    phase 1 for reads of any (per-read) length
+//                         + COUNT_NT2_READS_KERNEL<..LIST>   quads on the listed reads; without LIST: the single-kernel schedule
+//   locate                LOCATE_TILE_KERNEL<A>              hit -> row, sampled / verified hits finished
+//                         + LOCATE_WALK_NT_LANE_KERNEL       LF walks of the rest, one hit per lane, whole block per step
+//                         + LOCALISE_WALKED_KERNEL           record / offset of the walked hits
+//                         locate_walk_kernel<A>              generic walk (amino), locate_scalar_kernel<A> (round-1 baseline)
+//   accelerators          seed_level1/extend/finalize (+aa_*), seed_rows_to_positions_kernel, densify_sa_kernel,
+//                         nblock_sa_kernel, text4_scatter_kernel, text8_scatter_kernel
+//   glue                  pack_nt2_tile_kernel<R>, zero_listed_counts_kernel, scan_*_kernel, ref_kmer_table_kernel,
+//                         scalar_ops_kernel
 #pragma once
 #include <hip/hip_runtime.h>
 

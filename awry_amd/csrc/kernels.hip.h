@@ -856,6 +856,9 @@ __global__ __launch_bounds__(256) void count_nt2_probe_kernel(DevIndex ix, const
         else if (cnt == 1u && pos && seed_has_ctx(e) && i0 <= SEED_CTX_LEN) {
           // the entry holds the letters in front of the one occurrence: decided here, no text access
           value = (w & ((1ull << (2 * i0)) - 1)) == (uint64_t)(seed_ctx(e) >> (2 * (SEED_CTX_LEN - i0))) ? 1ull : 0ull;
+        } else if (cnt == 1u && pos && seed_has_ctx(e)) {
+          // more letters than the entry holds: the 14 nearest the seed window must agree before the text is asked
+          queued = ((w >> (2 * (i0 - SEED_CTX_LEN))) & ((1ull << (2 * SEED_CTX_LEN)) - 1)) == (uint64_t)seed_ctx(e);
         } else if (cnt == 1u) {
           const uint32_t nc = (uint32_t)(w >> (2 * (i0 - 1))) & 3u;
           survivor = seed_sym(e) == (int)(nc == 3u ? 5u : nc + 1u);  // else BWT[sp] is not the next letter: absent

@@ -82,6 +82,7 @@ def load_library():
     sig("awry_num_devices", i32, vp)
     sig("awry_replica_device", i32, vp, i32)
     sig("awry_count_batch", i32, vp, vp, u64p, u64, u64p)
+    sig("awry_count_packed_kmers", i32, vp, u64p, u64, i32, u64p)
     sig("awry_locate_batch", i32, vp, vp, u64p, u64, C.POINTER(u64p), C.POINTER(C.POINTER(Pos)), C.POINTER(u64p))
     sig("awry_free_buffer", None, vp)
     sig("awry_count", i32, vp, vp, u64, u64p)

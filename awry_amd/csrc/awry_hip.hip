@@ -1431,6 +1431,62 @@ int awry_count_batch(awry_index_t* idx, const uint8_t* qbytes, const uint64_t* q
   });
 }
 
+// k-mers that the caller already holds packed (letter j of a k-mer in bits [2j, 2j + 2) of its word, A0 C1 G2 T3): no
+// ASCII crosses PCIe, 16 B per query both ways instead of L + 8.
+int awry_count_packed_kmers(awry_index_t* idx, const uint64_t* words, uint64_t n, int L, uint64_t* counts_out) {
+  return guarded([&] {
+    require(idx && ((words && counts_out) || n == 0), "null argument");
+    require(L >= 1 && L <= 32, "packed k-mer length must be in 1..32");
+    for_each_replica(idx, n, [&](Replica& r, Shard sh, int) {
+      HIP_CHECK(hipSetDevice(r.device));
+      require(r.dev.alphabet == NUCLEOTIDE && r.dev.bwt_len < (1ull << 32) - 512, "packed k-mers need a nucleotide index with bwt_len < 2^32");
+      if (sh.hi <= sh.lo) return;
+      std::lock_guard<std::mutex> lane_lock(r.lane_mu);
+      std::unique_ptr<HostPin> pin_out;  // pinned by a helper thread while the first chunk is on its way (as in count_shard_packed)
+      std::thread pin_out_thread([&] {
+        (void)hipSetDevice(r.device);
+        pin_out.reset(new HostPin(counts_out + sh.lo, (sh.hi - sh.lo) * 8));
+      });
+      struct Joiner {
+        std::thread& t;
+        ~Joiner() { if (t.joinable()) t.join(); }
+      } joiner{pin_out_thread};
+      HostPin pin_in(words + sh.lo, (sh.hi - sh.lo) * 8);
+      const uint64_t CH = 4u << 20;
+      PackedLane* lanes = r.lanes;
+      struct Drain {
+        Replica& r;
+        ~Drain() {
+          for (int li = 0; li < 2; li++)
+            if (r.lanes[li].busy) { (void)hipStreamSynchronize(r.lane_stream[li]); r.lanes[li].busy = false; }
+        }
+      } drain{r};
+      for (int li = 0; li < 2; li++) {
+        PackedLane& ln = lanes[li];
+        ln.s = r.lane_stream[li];
+        if (!ln.done) HIP_CHECK(hipEventCreateWithFlags(&ln.done, hipEventDisableTiming));
+        const uint64_t cap = std::min<uint64_t>(CH, sh.hi - sh.lo);
+        if (ln.words.n < cap) ln.words.alloc(cap);
+        if (ln.counts.n < cap) ln.counts.alloc(cap);
+      }
+      int which = 0;
+      for (uint64_t lo = sh.lo; lo < sh.hi; lo += CH, which ^= 1) {
+        PackedLane& ln = lanes[which];
+        if (ln.busy) { HIP_CHECK(hipEventSynchronize(ln.done)); ln.busy = false; }
+        const uint64_t m = std::min(sh.hi, lo + CH) - lo;
+        HIP_CHECK(hipMemcpyAsync(ln.words.p, words + lo, m * 8, hipMemcpyHostToDevice, ln.s));
+        launch_count_nt2(r, ln.words.p, m, L, ln.counts.p, true, ln.s, nullptr);
+        if (pin_out_thread.joinable()) pin_out_thread.join();
+        HIP_CHECK(hipMemcpyAsync(counts_out + lo, ln.counts.p, m * 8, hipMemcpyDeviceToHost, ln.s));
+        HIP_CHECK(hipEventRecord(ln.done, ln.s));
+        ln.busy = true;
+      }
+      for (int li = 0; li < 2; li++)
+        if (lanes[li].busy) { HIP_CHECK(hipEventSynchronize(lanes[li].done)); lanes[li].busy = false; }
+    });
+  });
+}
+
 int awry_locate_batch(awry_index_t* idx, const uint8_t* qbytes, const uint64_t* qoff, uint64_t n, uint64_t** hit_off_out,
                       awry_pos_t** hits_out, uint64_t** global_pos_out) {
   return guarded([&] {

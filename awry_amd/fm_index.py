@@ -308,6 +308,13 @@ class FmIndex:
         _check(self._L.awry_count_batch(self._h, qb.ctypes.data, qo.ctypes.data_as(_u64p), n, out.ctypes.data_as(_u64p)))
         return out
 
+    def parallel_count_packed(self, words: np.ndarray, L: int) -> np.ndarray:
+        """k-mers already packed 2 bits per letter (letter j of a k-mer in bits [2j, 2j+2) of its uint64, A0 C1 G2 T3)"""
+        w = np.ascontiguousarray(words, dtype=np.uint64)
+        out = np.zeros(len(w), dtype=np.uint64)
+        _check(self._L.awry_count_packed_kmers(self._h, w.ctypes.data_as(_u64p), len(w), L, out.ctypes.data_as(_u64p)))
+        return out
+
     def parallel_count(self, queries: Iterable) -> np.ndarray:
         """src/fm_index.rs:455-460: counts in input order"""
         return self.parallel_count_csr(*pack_queries(queries))

@@ -109,6 +109,10 @@ int awry_num_devices(const awry_index_t *idx);
 /* FmIndex::parallel_count, src/fm_index.rs:455-460.  Query i = qbytes[qoff[i] .. qoff[i+1]); results in
  * input order in caller-owned counts_out[n].  Any undefined query => AWRY_ERR_INVALID_QUERY. */
 int awry_count_batch(awry_index_t *idx, const uint8_t *qbytes, const uint64_t *qoff, uint64_t n, uint64_t *counts_out);
+/* no counterpart in the reference: the same for callers that already hold their k-mers packed (k-mer counters do) --
+ * n k-mers of L <= 32 letters, letter j (0 = leftmost) of k-mer i in bits [2j, 2j + 2) of words[i], A0 C1 G2 T3;
+ * nucleotide indexes with bwt_len < 2^32.  16 B per query cross PCIe instead of L + 8. */
+int awry_count_packed_kmers(awry_index_t *idx, const uint64_t *words, uint64_t n, int L, uint64_t *counts_out);
 /* FmIndex::parallel_locate, src/fm_index.rs:479-487.  CSR output, library-allocated (awry_free_buffer):
  * hits of query i are [hit_off[i], hit_off[i+1]) in ascending BWT-row order (src/fm_index.rs:521);
  * global_pos (nullable) receives (SA sample + steps) % bwt_len (src/fm_index.rs:534). */

@@ -276,6 +276,22 @@ def test_host_batch_fast_path_equals_generic(oracle, L, monkeypatch):
     assert e.value.code == ERR_INVALID_QUERY
 
 
+def test_packed_kmer_host_entry_point(oracle):
+    """awry_count_packed_kmers: k-mers the caller already holds 2 bits per letter -- the ASCII entry point's counts"""
+    text, st, hd = synth.make_text(300000, 0, 4, 2, 0.02)
+    ix = gpu_index(text, 0, 8, 0, st, hd)
+    for L in (31, 32, 12, 1):
+        q2d = np.concatenate([synth.sampled_queries(text, 5000, L, L), synth.random_queries(5000, L, 0, L + 5)])
+        code = np.searchsorted(synth.NT, q2d).astype(np.uint64)
+        words = np.zeros(len(q2d), dtype=np.uint64)
+        for j in range(L):
+            words |= code[:, j] << np.uint64(2 * j)
+        want = ix.parallel_count_csr(*synth.fixed_to_csr(q2d))
+        assert np.array_equal(ix.parallel_count_packed(words, L), want), L
+    with pytest.raises(AwryError):
+        ix.parallel_count_packed(np.zeros(4, np.uint64), 33)
+
+
 def test_host_pipelines_over_many_chunks(oracle):
     """batches larger than one pipeline chunk (count: 4 M queries, locate: 1 M reads) alternate between the two stream
     lanes; a sprinkling of reads with N goes through the per-read fallback in every chunk.  Checked against the oracle

@@ -16,6 +16,15 @@ for L in (31, 101):
         t = time.perf_counter(); c = ix.parallel_count_csr(qb, qo); dt = time.perf_counter() - t
     print("fixed L=%d: %d queries in %.1f ms -> %.1f M queries/s end-to-end (PCIe-inclusive, %.2f GB/s in)" % (L, len(q2d), dt * 1e3, len(q2d) / dt / 1e6, qb.nbytes / dt / 1e9), flush=True)
     os.environ["X"] = "1"
+# packed k-mers from host memory: 16 B per query cross PCIe
+q2d = synth.random_queries(nq, 31, 0, 5)
+code = np.searchsorted(synth.NT, q2d).astype(np.uint64)
+words = np.zeros(nq, dtype=np.uint64)
+for j in range(31):
+    words |= code[:, j] << np.uint64(2 * j)
+for rep in range(3):
+    t = time.perf_counter(); c = ix.parallel_count_packed(words, 31); dt = time.perf_counter() - t
+print("packed 31-mers: %d queries in %.1f ms -> %.1f M queries/s end-to-end (PCIe-inclusive)" % (nq, dt * 1e3, nq / dt / 1e6), flush=True)
 # generic path: ragged lengths
 lens = np.random.default_rng(1).integers(20, 40, size=nq // 4)
 qo = np.zeros(len(lens) + 1, dtype=np.uint64); qo[1:] = np.cumsum(lens)

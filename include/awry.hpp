@@ -123,6 +123,12 @@ class FmIndex {
     check(awry_count_batch(h_, bytes.data(), off.data(), out.size(), out.data()));
     return out;
   }
+  // no counterpart in the reference: k-mers already packed 2 bits per letter (awry_count_packed_kmers)
+  std::vector<uint64_t> parallel_count_packed(const std::vector<uint64_t>& words, int L) {
+    std::vector<uint64_t> out(words.size());
+    check(awry_count_packed_kmers(h_, words.data(), words.size(), L, out.data()));
+    return out;
+  }
   template <class StrRange>
   std::vector<std::vector<LocalizedSequencePosition>> parallel_locate(const StrRange& queries) {
     std::vector<uint8_t> bytes; std::vector<uint64_t> off;

@@ -965,6 +965,19 @@ void count_shard_generic(Replica& r, const uint8_t* qbytes, const uint64_t* qoff
   }
 }
 
+// memcpy for result-sized buffers: fresh destination pages fault on first touch, so large copies are cut over a few threads
+void par_memcpy(void* dst, const void* src, size_t bytes) {
+  const unsigned T = bytes >= (32u << 20) ? std::min(8u, std::max(1u, std::thread::hardware_concurrency())) : 1;
+  if (T == 1) { memcpy(dst, src, bytes); return; }
+  std::vector<std::thread> th;
+  const size_t per = ((bytes + T - 1) / T + 4095) & ~(size_t)4095;
+  for (unsigned t = 0; t < T; t++) {
+    const size_t lo = std::min(bytes, per * t), hi = std::min(bytes, per * (t + 1));
+    if (hi > lo) th.emplace_back([=] { memcpy(static_cast<char*>(dst) + lo, static_cast<const char*>(src) + lo, hi - lo); });
+  }
+  for (auto& x : th) x.join();
+}
+
 template <class T>
 struct MBuf {  // malloc'ed, geometrically growing array whose storage can be handed to the caller (awry_free_buffer = free)
   T* p = nullptr;
@@ -1004,10 +1017,10 @@ struct LocateResult {  // per shard, in query order
       if (want_gpos) gpos.grow(est);
     }
     pos.grow(total + n);
-    memcpy(pos.p + total, p, n * sizeof(awry_pos_t));
+    par_memcpy(pos.p + total, p, n * sizeof(awry_pos_t));
     if (want_gpos) {
       gpos.grow(total + n);
-      memcpy(gpos.p + total, g, n * 8);
+      par_memcpy(gpos.p + total, g, n * 8);
     }
     total += n;
   }

@@ -31,3 +31,13 @@ print("index + replica %.1f s, seed k=%d" % (time.time() - t, ix.seed_kmer_len()
 dev = torch.device("cuda", 0)
 out = bench.locate_benchmark(ix, text, torch, dev, torch.cuda.current_stream().cuda_stream, nr, 101)
 print(json.dumps({k: v for k, v in out.items() if k != "cpu_baseline"}, indent=1))
+# the host boundary on the same reads (offsets, positions and (record, offset) pairs back in host memory)
+reads = synth.sampled_queries(text, 1_000_000, 101, 4242)
+qb, qo = synth.fixed_to_csr(reads)
+for rep in range(2):
+    t = time.perf_counter(); off, g, p = ix.parallel_locate_csr(qb, qo); dt = time.perf_counter() - t
+print("host locate: %d reads, %d hits in %.1f ms -> %.1f M reads/s, %.1f M hits/s (PCIe-inclusive)" % (len(reads), len(g), dt * 1e3, len(reads) / dt / 1e6, len(g) / dt / 1e6))
+chk = np.random.default_rng(1).integers(0, len(g), size=200000)
+qi = np.repeat(np.arange(len(reads)), np.diff(off).astype(np.int64))
+assert np.array_equal(text[g[chk].astype(np.int64)[:, None] + np.arange(101)[None, :]], reads[qi[chk]])
+print("every sampled location holds its read")

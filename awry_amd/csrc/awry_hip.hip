@@ -268,6 +268,7 @@ void build_seed(awry_index* ix, Replica& r, int k) {
   r.dev.seed = nullptr;
   r.dev.seed_k = 0;
   r.dev.seed_pos = 0;
+  r.dev.ctx_extra = 0;
   if (k <= 0) return;
   require(narrow(ix->host), "seed table needs an index with bwt_len < 2^32");
   const bool nt = ix->host.alphabet == NUCLEOTIDE;
@@ -321,8 +322,11 @@ void sync_seed_mode(awry_index* ix, Replica& r) {
   }
   uint64_t nfinal = 1;
   for (int j = 0; j < r.seed_k; j++) nfinal *= nt ? 4 : 20;
+  // context letters beyond the 14 of the count field ride in the top bits of sp that positions of this text never use
+  const int extra = nt ? (int)std::min<uint64_t>(15, (32 - std::min<uint64_t>(32, h.sa_bits)) / 2) : 0;
   hipLaunchKernelGGL(seed_rows_to_positions_kernel, dim3(grid_for(r, nfinal, 256)), dim3(256), 0, r.stream, r.seed.p, nfinal, r.dense_sa.p,
-                     nt ? SEED_CNT_SAT : AA_SEED_CNT_SAT, nt ? r.dev.text4 : nullptr);
+                     nt ? SEED_CNT_SAT : AA_SEED_CNT_SAT, nt ? r.dev.text4 : nullptr, extra);
+  r.dev.ctx_extra = (uint32_t)extra;
   HIP_CHECK(hipGetLastError());
   HIP_CHECK(hipStreamSynchronize(r.stream));
   r.dev.seed_pos = 1;
@@ -374,6 +378,7 @@ std::unique_ptr<Replica> make_replica(awry_index* ix, int device) {
   d.verify_after = 0;
   d.sa_nblock = nullptr;
   d.seed_pos = 0;
+  d.ctx_extra = 0;
   build_seed(ix, *r, ix->seed_k_request < 0 ? default_seed_k(h) : ix->seed_k_request);
   build_dense_sa(ix, *r, ix->dense_ratio_request);
   int vreq = ix->verify_request;

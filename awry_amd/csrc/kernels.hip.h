@@ -227,7 +227,7 @@ __global__ __launch_bounds__(256) void count_scalar_kernel(DevIndex ix, const ui
           // the query by its symbol or to finish it against the text, not to continue the search: without the text
           // such a query starts over without the table
           if (ix.seed_pos && scnt == 1 && !wrong_sym) {
-            const uint64_t rem = e - k - b, p = se.sp;
+            const uint64_t rem = e - k - b, p = seed_position(se, (int)ix.ctx_extra);
             if (allow_verify && ix.text8 && rem < 65536) {
               bool same = p >= rem;  // else the suffix starts too close to the text's beginning
               ByteStream t(ix.text8 + (p - rem));
@@ -793,6 +793,7 @@ __global__ __launch_bounds__(256) void count_nt2_probe_kernel(DevIndex ix, const
   const uint64_t lane_lt = (1ull << lane) - 1;
   const uint64_t region = (uint64_t)blockIdx.x * sv.cap;
   const bool pos = VERIFY && ix.seed_pos;   // singleton entries hold SA[row]: no SA read, and no row to step from
+  const int cx = (int)ix.ctx_extra, clen = SEED_CTX_LEN + cx;  // letters in front of the occurrence a context entry holds
   const bool verify = VERIFY && (i0 >= 3 || (pos && i0 >= 1));
   int vcount = 0;  // wave-uniform fill of this wave's queue
   uint32_t t_vsa = 0, t_vtxt = 0;
@@ -853,12 +854,12 @@ __global__ __launch_bounds__(256) void count_nt2_probe_kernel(DevIndex ix, const
         if (cnt == SEED_CNT_SAT) survivor = true;
         else if (cnt == 0u) value = 0;
         else if (i0 == 0) value = cnt;
-        else if (cnt == 1u && pos && seed_has_ctx(e) && i0 <= SEED_CTX_LEN) {
+        else if (cnt == 1u && pos && seed_has_ctx(e) && i0 <= clen) {
           // the entry holds the letters in front of the one occurrence: decided here, no text access
-          value = (w & ((1ull << (2 * i0)) - 1)) == (uint64_t)(seed_ctx(e) >> (2 * (SEED_CTX_LEN - i0))) ? 1ull : 0ull;
+          value = (w & ((1ull << (2 * i0)) - 1)) == (seed_full_ctx(e, cx) >> (2 * (clen - i0))) ? 1ull : 0ull;
         } else if (cnt == 1u && pos && seed_has_ctx(e)) {
-          // more letters than the entry holds: the 14 nearest the seed window must agree before the text is asked
-          queued = ((w >> (2 * (i0 - SEED_CTX_LEN))) & ((1ull << (2 * SEED_CTX_LEN)) - 1)) == (uint64_t)seed_ctx(e);
+          // more letters than the entry holds: those nearest the seed window must agree before the text is asked
+          queued = ((w >> (2 * (i0 - clen))) & ((1ull << (2 * clen)) - 1)) == seed_full_ctx(e, cx);
         } else if (cnt == 1u) {
           const uint32_t nc = (uint32_t)(w >> (2 * (i0 - 1))) & 3u;
           survivor = seed_sym(e) == (int)(nc == 3u ? 5u : nc + 1u);  // else BWT[sp] is not the next letter: absent
@@ -874,7 +875,7 @@ __global__ __launch_bounds__(256) void count_nt2_probe_kernel(DevIndex ix, const
           if (queued) {
             const int s = vcount + (int)__popcll(qm & lane_lt);
             s_vw[wv_id][s] = w;
-            s_vsp[wv_id][s] = e.sp;
+            s_vsp[wv_id][s] = cnt == 1u && pos ? seed_position(e, cx) : e.sp;
             s_vq[wv_id][s] = (uint32_t)q;
             s_vn[wv_id][s] = (uint8_t)cnt;
           }
@@ -1151,30 +1152,39 @@ __global__ __launch_bounds__(256) void seed_finalize_kernel(DevIndex ix, SeedEnt
 // Position seeds (DevIndex::seed_pos): every singleton entry's row is replaced by the text position of that row's
 // suffix.  A query whose seed window occurs once in the text then needs no SA read: the entry itself says where the
 // single candidate is, and the text decides (2 random lines per such query instead of 3).
-// text4 != nullptr (nucleotide): where the SEED_CTX_LEN letters in front of the occurrence exist and are all ACGT they
-// go into the entry as well (SEED_CTX, layout.h).
+// text4 != nullptr (nucleotide): where the SEED_CTX_LEN + extra letters in front of the occurrence exist and are all
+// ACGT they go into the entry as well (SEED_CTX, layout.h).
 __global__ __launch_bounds__(256) void seed_rows_to_positions_kernel(SeedEntry* __restrict__ table, uint64_t nentries,
                                                                      const uint32_t* __restrict__ dense_sa, uint32_t cnt_mask,
-                                                                     const uint32_t* __restrict__ text4) {
+                                                                     const uint32_t* __restrict__ text4, int extra) {
   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  const int clen = SEED_CTX_LEN + extra;  // <= 30
+  auto letters16 = [](uint64_t x) {  // 16 nibbles -> 16 2-bit letters
+    x &= 0x3333333333333333ull;
+    x = (x | (x >> 2)) & 0x0F0F0F0F0F0F0F0Full;
+    x = (x | (x >> 4)) & 0x00FF00FF00FF00FFull;
+    x = (x | (x >> 8)) & 0x0000FFFF0000FFFFull;
+    return (x | (x >> 16)) & 0x00000000FFFFFFFFull;
+  };
   for (uint64_t o = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; o < nentries; o += stride) {
     SeedEntry e = table[o];
     if ((e.cnt & cnt_mask) != 1u) continue;  // cnt_mask: SEED_CNT_SAT (nt) / AA_SEED_CNT_SAT (aa)
     const uint32_t p = dense_sa[e.sp];
     e.sp = p;
-    if (text4 && p >= (uint32_t)SEED_CTX_LEN) {
-      const uint64_t t0 = (uint64_t)p - SEED_CTX_LEN;  // 14 nibbles from nibble t0: at most three words
-      const uint32_t* wp = text4 + (t0 >> 3);
+    if (text4 && p >= (uint32_t)clen) {
+      const uint64_t t0 = (uint64_t)p - clen;  // clen nibbles from nibble t0: at most five words
+      const Text20 t = *reinterpret_cast<const Text20*>(text4 + (t0 >> 3));
       const int sh = 4 * (int)(t0 & 7);
-      const uint64_t a0 = (uint64_t)wp[0] | ((uint64_t)wp[1] << 32), a1 = wp[2];
-      uint64_t x = (sh ? (a0 >> sh) | (a1 << (64 - sh)) : a0) & 0x00FFFFFFFFFFFFFFull;
-      if ((x & 0x0088888888888888ull) == 0) {  // all fourteen are A, C, G or T: nibbles -> 2-bit letters
-        x &= 0x3333333333333333ull;
-        x = (x | (x >> 2)) & 0x0F0F0F0F0F0F0F0Full;
-        x = (x | (x >> 4)) & 0x00FF00FF00FF00FFull;
-        x = (x | (x >> 8)) & 0x0000FFFF0000FFFFull;
-        x = (x | (x >> 16)) & 0x00000000FFFFFFFFull;
-        e.cnt = (e.cnt & 0xE0000000u) | SEED_CTX | (uint32_t)x;
+      const uint64_t a0 = (uint64_t)t.w[0] | ((uint64_t)t.w[1] << 32), a1 = (uint64_t)t.w[2] | ((uint64_t)t.w[3] << 32), a2w = t.w[4];
+      const uint64_t lo = sh ? (a0 >> sh) | (a1 << (64 - sh)) : a0;   // nibbles 0..15
+      uint64_t hi = sh ? (a1 >> sh) | (a2w << (64 - sh)) : a1;         // nibbles 16..31
+      hi &= clen > 16 ? (~0ull >> (4 * (32 - clen))) : 0ull;          // only the first clen nibbles count
+      const uint64_t lo_used = clen >= 16 ? lo : (lo & ((1ull << (4 * clen)) - 1));
+      if (((lo_used | hi) & 0x8888888888888888ull) == 0) {  // all of them are A, C, G or T
+        const uint64_t full = letters16(lo_used) | (letters16(hi) << 32);  // text[p - clen + j] in bits [2j, 2j + 2)
+        const uint32_t far = extra ? (uint32_t)(full & ((1ull << (2 * extra)) - 1)) : 0u;
+        e.sp = p | (extra ? far << (32 - 2 * extra) : 0u);
+        e.cnt = (e.cnt & 0xE0000000u) | SEED_CTX | (uint32_t)((full >> (2 * extra)) & SEED_CNT_SAT);
       }
     }
     table[o] = e;
@@ -1383,9 +1393,9 @@ __global__ __launch_bounds__(256) void count_nt2_reads_kernel(DevIndex ix, const
             // position seed: e.sp is SA[row], the text position of the single candidate -- there is no row to step from
             if (i == 0) {  // the read is the seed window itself
               pos_hit = true;
-              vp = e.sp;
+              vp = seed_position(e, (int)ix.ctx_extra);
             } else if (VERIFY && i < 65536) {  // straight to the text, no SA read
-              vp = e.sp;
+              vp = seed_position(e, (int)ix.ctx_extra);
               sp = ep = 0u;  // one candidate, index 0
               vj = 0;
               vmask = 0;
@@ -1483,6 +1493,7 @@ __global__ __launch_bounds__(256) void count_nt2_reads_probe_kernel(DevIndex ix,
   const int k = ix.seed_k, W = (L + 31) / 32;  // RAGGED: L is the longest read, W the stride
   const bool pos = ix.seed_pos != 0;           // singleton entries hold SA[row]: no SA read, and no row to step from
   const int min_i0 = pos ? 1 : 3;              // fewest letters left of the seed window worth (or, with pos, needing) the text
+  const int cx = (int)ix.ctx_extra, clen = SEED_CTX_LEN + cx;  // letters in front of the occurrence a context entry holds
   const uint64_t kmask = (1ull << (2 * k)) - 1;
   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
   const uint64_t lane_lt = (1ull << lane) - 1;
@@ -1563,18 +1574,19 @@ __global__ __launch_bounds__(256) void count_nt2_reads_probe_kernel(DevIndex ix,
       } else if (valid) {
         if (cnt == 0u) settle(qv[h], 0, (RS_PLAIN << RS_MODE_SHIFT) | 1ull);
         else if (cnt == 1u && pos && seed_has_ctx(e)) {
-          // the entry holds the 14 letters in front of the one occurrence: a read with no more than that left of its
-          // seed window is decided here; a longer one goes on to the text only if those 14 agree
+          // the entry holds the letters in front of the one occurrence: a read with no more than that left of its
+          // seed window is decided here; a longer one goes on to the text only if they agree
           const int i0 = (RAGGED ? (int)lens[qv[h]] : L) - k;
           const uint64_t* qw = queries + qv[h] * W;
-          if (i0 <= SEED_CTX_LEN) {
-            const bool same = (qw[0] & ((1ull << (2 * i0)) - 1)) == (uint64_t)(seed_ctx(e) >> (2 * (SEED_CTX_LEN - i0)));
-            settle(qv[h], same ? 1 : 0, same ? ((RS_SINGLE << RS_MODE_SHIFT) | (uint64_t)(e.sp - (uint32_t)i0)) : ((RS_PLAIN << RS_MODE_SHIFT) | 1ull));
+          if (i0 <= clen) {
+            const bool same = (qw[0] & ((1ull << (2 * i0)) - 1)) == (seed_full_ctx(e, cx) >> (2 * (clen - i0)));
+            settle(qv[h], same ? 1 : 0,
+                   same ? ((RS_SINGLE << RS_MODE_SHIFT) | (uint64_t)(seed_position(e, cx) - (uint32_t)i0)) : ((RS_PLAIN << RS_MODE_SHIFT) | 1ull));
           } else {
-            const int f = i0 - SEED_CTX_LEN, a = f >> 5, sh = 2 * (f & 31);
+            const int f = i0 - clen, a = f >> 5, sh = 2 * (f & 31);
             uint64_t x = qw[a] >> sh;
             if (sh && a + 1 < W) x |= qw[a + 1] << (64 - sh);
-            queued = (x & ((1ull << (2 * SEED_CTX_LEN)) - 1)) == (uint64_t)seed_ctx(e);
+            queued = (x & ((1ull << (2 * clen)) - 1)) == seed_full_ctx(e, cx);
             if (!queued) settle(qv[h], 0, (RS_PLAIN << RS_MODE_SHIFT) | 1ull);
           }
         } else if (cnt == 1u) {
@@ -1588,7 +1600,7 @@ __global__ __launch_bounds__(256) void count_nt2_reads_probe_kernel(DevIndex ix,
       if (qm) {
         if (queued) {
           const int s = vcount + (int)__popcll(qm & lane_lt);
-          s_vsp[wv_id][s] = e.sp;
+          s_vsp[wv_id][s] = cnt == 1u && pos ? seed_position(e, cx) : e.sp;
           s_vq[wv_id][s] = (uint32_t)qv[h];
           s_vn[wv_id][s] = (uint8_t)cnt;
         }

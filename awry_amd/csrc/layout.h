@@ -70,7 +70,10 @@ AWRY_HD int nt_index_of_letter(int l) { return l == 3 ? 5 : l + 1; }
 // With position seeds (DevIndex::seed_pos) a singleton's sp is the text position p of its one occurrence, and bit 28
 // (SEED_CTX) says that bits 0..27 hold the SEED_CTX_LEN = 14 letters in front of it instead of the count 1:
 // text[p - 14 + j] in bits [2j, 2j + 2) -- the orientation of a packed query word -- so that a 31-mer probed with
-// k = 17 is decided by its entry alone.  Set only where those 14 positions exist and are all ACGT.
+// k = 17 is decided by its entry alone.  A text shorter than 2^32 leaves the top bits of p unused: they hold E =
+// DevIndex::ctx_extra further letters, text[p - 14 - E + j] in bits [32 - 2E + 2j, ...) of sp.  With the default
+// k = floor(log4 n) + 2 that makes 14 + E >= 31 - k for every text size: 31-mers are always decided by the entry.
+// Set only where all 14 + E positions exist and are ACGT.
 struct SeedEntry { uint32_t sp, cnt; };
 constexpr uint32_t SEED_CNT_SAT = 0x0FFFFFFFu;
 constexpr uint32_t SEED_CTX = 0x10000000u;
@@ -78,6 +81,12 @@ constexpr int SEED_CTX_LEN = 14;
 AWRY_HD bool seed_has_ctx(SeedEntry e) { return (e.cnt & SEED_CTX) != 0; }
 AWRY_HD uint32_t seed_cnt(SeedEntry e) { return seed_has_ctx(e) ? 1u : (e.cnt & SEED_CNT_SAT); }
 AWRY_HD uint32_t seed_ctx(SeedEntry e) { return e.cnt & SEED_CNT_SAT; }
+// text position of a position seed (extra = DevIndex::ctx_extra)
+AWRY_HD uint32_t seed_position(SeedEntry e, int extra) { return extra && seed_has_ctx(e) ? e.sp & (0xFFFFFFFFu >> (2 * extra)) : e.sp; }
+// all 14 + extra letters in front of the occurrence, text[p - 14 - extra + j] in bits [2j, 2j + 2)
+AWRY_HD uint64_t seed_full_ctx(SeedEntry e, int extra) {
+  return (extra ? (uint64_t)(e.sp >> (32 - 2 * extra)) : 0ull) | ((uint64_t)seed_ctx(e) << (2 * extra));
+}
 AWRY_HD int seed_sym(SeedEntry e) { return (int)(e.cnt >> 29); }
 
 // amino seed entries: count in bits 0..26 (saturating), 5-bit symbol index of a singleton's BWT row in bits 27..31
@@ -102,6 +111,7 @@ struct DevIndex {
   uint32_t verify_after;      // seed-and-verify: switch from LF steps to text comparison after this many steps
   const uint8_t* text8;       // the text as symbol indices (0 = '$'), one byte per position: lets the generic kernel finish a
                               //   query against the text like the packed kernels do, for any alphabet and any letters
+  uint32_t ctx_extra;         // E: context letters kept in the unused top bits of a position seed's sp (layout.h, SeedEntry)
   uint32_t seed_pos;          // 1: singleton seed entries hold the TEXT POSITION SA[row] in .sp instead of the row (kept only
                               //   while the verify accelerators are resident and the two-phase schedules are the policy)
   const uint32_t* sa_nblock;  // SA of every row whose suffix starts with N (rows [C[N], C[T])), or nullptr: ends locate

@@ -1,5 +1,6 @@
 #!/bin/bash
 # on the GPU box: gather calibration, plain and under rocprofv3 --pmc FETCH_SIZE (separate pass, kernel-trace only)
+# build first (works without a GPU): mkdir -p tools/bin && hipcc --offload-arch=gfx950 -O3 tools/calib_gather.hip -o tools/bin/calib_gather
 set -o pipefail
 cd "$GRAFT_REPO_ROOT"; export TMPDIR=/tmp
 OUT=gpurun_out/calib; mkdir -p $OUT

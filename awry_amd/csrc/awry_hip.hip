@@ -468,8 +468,11 @@ void launch_locate(Replica& r, const uint64_t* d_range_start, int rs_stride, con
   unsigned long long* wctr = next_counter(r, s);
   const dim3 gw(grid_for(r, total, 256, 7));
   static const bool generic_walk = getenv("AWRY_LOCATE_WALK") && !strcmp(getenv("AWRY_LOCATE_WALK"), "generic");
-  if (r.dev.alphabet == NUCLEOTIDE && !generic_walk)
-    hipLaunchKernelGGL(locate_walk_nt_lane_kernel, dim3(grid_for(r, total, 256, 8)), b, 0, s, r.dev, total, dense, r.dense_ratio, d_gpos, wctr);
+  static const bool direct_walk = getenv("AWRY_LOCATE_WALK") && !strcmp(getenv("AWRY_LOCATE_WALK"), "direct");
+  if (r.dev.alphabet == NUCLEOTIDE && !generic_walk && !direct_walk)
+    hipLaunchKernelGGL(locate_walk_nt_lane_kernel<true>, dim3(grid_for(r, total, 256, 4)), b, 0, s, r.dev, total, dense, r.dense_ratio, d_gpos, wctr);
+  else if (r.dev.alphabet == NUCLEOTIDE && !generic_walk)
+    hipLaunchKernelGGL(locate_walk_nt_lane_kernel<false>, dim3(grid_for(r, total, 256, 8)), b, 0, s, r.dev, total, dense, r.dense_ratio, d_gpos, wctr);
   else if (r.dev.alphabet == NUCLEOTIDE) hipLaunchKernelGGL(locate_walk_kernel<NUCLEOTIDE>, gw, b, 0, s, r.dev, total, dense, r.dense_ratio, d_gpos, d_pos, wctr);
   else hipLaunchKernelGGL(locate_walk_kernel<AMINO>, gw, b, 0, s, r.dev, total, dense, r.dense_ratio, d_gpos, d_pos, wctr);
   if (d_pos) hipLaunchKernelGGL(localise_walked_kernel, dim3(grid_for(r, total, 256)), b, 0, s, r.dev, total, d_gpos, d_pos);

@@ -1891,10 +1891,16 @@ __global__ __launch_bounds__(256) void nblock_sa_kernel(DevIndex ix, uint64_t ns
 // kernel 1.91 ms; this kernel 1.50 ms; a quad-cooperative variant (4 lanes per hit, 2 loads per lane, DPP reductions)
 // 1.65 ms -- it was instruction-bound (~230 instructions per 16 steps), this one is bound by the texture path's
 // per-lane line lookups (8 per step).
+// LDS_SHARE: the blocks of a wave's 64 walks are fetched cooperatively -- eight lanes per block, so that one load
+// instruction covers eight whole 128-B lines instead of 64 sixteen-byte pieces of 64 different lines (an eighth of the
+// line lookups in the texture path) -- and handed to their lanes through a wave-private LDS tile.
+template <bool LDS_SHARE>
 __global__ __launch_bounds__(256) void locate_walk_nt_lane_kernel(DevIndex ix, uint64_t total, const uint32_t* __restrict__ dense,
                                                                   uint32_t dense_ratio, uint64_t* __restrict__ gpos,
                                                                   unsigned long long* __restrict__ batch_counter) {
-  const int lane = threadIdx.x & 63;
+  constexpr int ROW = 9;  // 16-B pieces per tile row: 8 + 1 of padding against bank conflicts
+  __shared__ ulonglong2 s_blk[LDS_SHARE ? 4 : 1][LDS_SHARE ? 64 * ROW : 1];
+  const int lane = threadIdx.x & 63, wv_id = threadIdx.x >> 6;
   const uint64_t lane_lt = (1ull << lane) - 1;
   const uint64_t* __restrict__ blocks = ix.blocks;
   const uint64_t cA = ix.prefix_sums[1], cC = ix.prefix_sums[2], cG = ix.prefix_sums[3], cN = ix.prefix_sums[4], cT = ix.prefix_sums[5];
@@ -1933,7 +1939,18 @@ __global__ __launch_bounds__(256) void locate_walk_nt_lane_kernel(DevIndex ix, u
 #pragma unroll
     for (int j = 0; j < 8; j++) B[j] = ulonglong2{0, 0};
     if (state == FETCH) v = gpos[h];
-    if (state == WALK) {
+    const uint64_t wm = LDS_SHARE ? __ballot(state == WALK) : 0ull;
+    if (LDS_SHARE) {
+      if (wm) {  // round r: the eight lanes 8j..8j+7 fetch the block of lane 8r + j, one 16-B piece each
+        const unsigned long long myblk = state == WALK ? (unsigned long long)(row >> 8) : 0ull;
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+          const int src = 8 * r + (lane >> 3);
+          const unsigned long long b = __shfl(myblk, src, 64);
+          if ((wm >> src) & 1ull) B[r] = reinterpret_cast<const ulonglong2*>(blocks + b * NT_BLOCK_WORDS)[lane & 7];
+        }
+      }
+    } else if (state == WALK) {
       const ulonglong2* p = reinterpret_cast<const ulonglong2*>(blocks + (row >> 8) * NT_BLOCK_WORDS);
 #pragma unroll
       for (int j = 0; j < 8; j++) B[j] = p[j];
@@ -1953,6 +1970,17 @@ __global__ __launch_bounds__(256) void locate_walk_nt_lane_kernel(DevIndex ix, u
     asm volatile("" : "+v"(v), "+v"(s0), "+v"(s1), "+v"(B[0].x), "+v"(B[0].y), "+v"(B[1].x), "+v"(B[1].y), "+v"(B[2].x), "+v"(B[2].y),
                  "+v"(B[3].x), "+v"(B[3].y), "+v"(B[4].x), "+v"(B[4].y), "+v"(B[5].x), "+v"(B[5].y), "+v"(B[6].x), "+v"(B[6].y),
                  "+v"(B[7].x), "+v"(B[7].y));
+    if (LDS_SHARE && wm) {  // pieces -> tile, then every walking lane picks up its own block
+#pragma unroll
+      for (int r = 0; r < 8; r++) s_blk[wv_id][(8 * r + (lane >> 3)) * ROW + (lane & 7)] = B[r];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      if (state == WALK) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) B[j] = s_blk[wv_id][lane * ROW + j];
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
     // ---- consume
     if (state == FETCH) {
       if (v & LOC_WALK_FLAG) { row = v & ~LOC_WALK_FLAG; steps = 0; state = stops(row) ? EMIT : WALK; }

@@ -147,6 +147,21 @@ struct Replica {
   PackedLane lanes[2];
   LocateLane loc_lanes[2];
   std::mutex lane_mu;  // one packed host call at a time per replica
+  // single-query calls (count_string, search_range): a pinned mailbox the generic kernel reads and writes in place --
+  // one launch and one stream synchronisation per call, no device allocation, no copies
+  struct Mailbox {
+    static constexpr size_t QCAP = 1 << 16;
+    static constexpr size_t HCAP = 1 << 15;  // hits a single-query locate returns through the mailbox
+    uint8_t* q = nullptr;       // [QCAP + 16]
+    uint64_t* words = nullptr;  // off[2], count, range[2], status, hit_off[2]
+    uint64_t* gpos = nullptr;   // [HCAP]
+    uint64_t* pos = nullptr;    // [2 * HCAP]
+    ~Mailbox() {
+      for (void* p : {(void*)q, (void*)words, (void*)gpos, (void*)pos})
+        if (p) (void)hipHostFree(p);
+    }
+  } mailbox;
+  std::mutex mailbox_mu;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   DevBuf<uint64_t> blocks, sa_words, seq_starts;
   DevBuf<SeedEntry> seed;
@@ -1548,7 +1563,42 @@ int awry_locate_batch(awry_index_t* idx, const uint8_t* qbytes, const uint64_t* 
 
 void awry_free_buffer(void* p) { free(p); }
 
+namespace {
+// one query through the replica's pinned mailbox; want_rows: the range must be a row interval (no text shortcut)
+// (the caller holds r.mailbox_mu)
+void single_query(Replica& r, const uint8_t* q, uint64_t len, bool want_rows, uint64_t& count, uint64_t& start, uint64_t& end) {
+  Replica::Mailbox& m = r.mailbox;
+  if (!m.q) {
+    HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&m.q), Replica::Mailbox::QCAP + 16, hipHostMallocDefault));
+    HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&m.words), 8 * 8, hipHostMallocDefault));
+    HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&m.gpos), Replica::Mailbox::HCAP * 8, hipHostMallocDefault));
+    HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&m.pos), Replica::Mailbox::HCAP * 16, hipHostMallocDefault));
+  }
+  if (len) memcpy(m.q, q, len);
+  m.words[0] = 0;
+  m.words[1] = len;
+  uint8_t* status = reinterpret_cast<uint8_t*>(m.words + 5);
+  launch_count_ascii(r, m.q, m.words, 1, m.words + 2, m.words + 3, status, r.stream, !want_rows);
+  HIP_CHECK(hipStreamSynchronize(r.stream));
+  if (*status != Q_OK) {
+    ChunkBuffers cb;
+    cb.h_status.assign(1, *status);
+    check_status(cb, 0);  // raises INVALID_QUERY with the usual message
+  }
+  count = m.words[2];
+  start = m.words[3];
+  end = m.words[4];
+}
+}  // namespace
+
 int awry_count(awry_index_t* idx, const uint8_t* q, uint64_t len, uint64_t* count) {
+  if (idx && count && idx->reps.size() == 1 && (q || len == 0) && len <= Replica::Mailbox::QCAP)
+    return guarded([&] {
+      uint64_t a = 0, b = 0;
+      Replica& r = replica(idx, 0);
+      std::lock_guard<std::mutex> lock(r.mailbox_mu);
+      single_query(r, q, len, false, *count, a, b);
+    });
   const uint64_t off[2] = {0, len};
   return awry_count_batch(idx, q, off, 1, count);
 }
@@ -1557,6 +1607,12 @@ int awry_search_range(awry_index_t* idx, const uint8_t* q, uint64_t len, awry_ra
   return guarded([&] {
     require(idx && out && (q || len == 0), "null argument");
     Replica& r = replica(idx, 0);
+    if (len <= Replica::Mailbox::QCAP) {
+      uint64_t c = 0;
+      std::lock_guard<std::mutex> lock(r.mailbox_mu);
+      single_query(r, q, len, true, c, out->start_ptr, out->end_ptr);
+      return;
+    }
     ChunkBuffers cb;
     const uint64_t off[2] = {0, len};
     run_count_chunk(r, cb, q, off, Shard{0, 1}, true, false);  // the caller wants rows
@@ -1571,6 +1627,33 @@ int awry_search_range(awry_index_t* idx, const uint8_t* q, uint64_t len, awry_ra
 
 int awry_locate(awry_index_t* idx, const uint8_t* q, uint64_t len, awry_pos_t** hits_out, uint64_t** global_pos_out,
                 uint64_t* n_hits) {
+  if (idx && hits_out && idx->reps.size() == 1 && (q || len == 0) && len <= Replica::Mailbox::QCAP) {
+    // one query: count through the mailbox, then -- for a hit list that fits it -- locate straight into pinned memory
+    bool done = false;
+    int rc = guarded([&] {
+      Replica& r = replica(idx, 0);
+      std::lock_guard<std::mutex> lock(r.mailbox_mu);
+      uint64_t count = 0, rs = 0, unused = 0;
+      single_query(r, q, len, false, count, rs, unused);
+      if (count > Replica::Mailbox::HCAP) return;  // the batch path sizes its own buffers
+      Replica::Mailbox& m = r.mailbox;
+      std::unique_ptr<awry_pos_t, decltype(&free)> hits(malloc_array<awry_pos_t>(count), &free);
+      std::unique_ptr<uint64_t, decltype(&free)> gp(global_pos_out ? malloc_array<uint64_t>(count) : nullptr, &free);
+      if (count) {
+        m.words[6] = 0;
+        m.words[7] = count;
+        launch_locate(r, m.words + 3, 2, m.words + 6, 1, count, m.gpos, m.pos, r.stream);
+        HIP_CHECK(hipStreamSynchronize(r.stream));
+        memcpy(hits.get(), m.pos, count * sizeof(awry_pos_t));
+        if (gp) memcpy(gp.get(), m.gpos, count * 8);
+      }
+      *hits_out = hits.release();
+      if (global_pos_out) *global_pos_out = gp.release();
+      if (n_hits) *n_hits = count;
+      done = true;
+    });
+    if (rc != AWRY_OK || done) return rc;
+  }
   const uint64_t off[2] = {0, len};
   uint64_t* hit_off = nullptr;
   int rc = awry_locate_batch(idx, q, off, 1, &hit_off, hits_out, global_pos_out);

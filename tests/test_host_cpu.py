@@ -228,3 +228,19 @@ def test_sequence_file_reader_parallel_chunks(tmp_path, oracle):
     want = FmIndex.from_text(text, 0, 8, 4, [int(x) for x in starts], ["chr%d" % i for i in range(len(recs))], build_device=awry_amd.fm_index.BUILD_HOST)
     assert ix.bwt_len() == want.bwt_len() and np.array_equal(ix.device_block_words(), want.device_block_words())
     assert ix.sequences() == want.sequences() and np.array_equal(ix.sa_words(), want.sa_words())
+
+
+def test_c_abi_header_is_plain_c(tmp_path):
+    """include/awry_hip.h compiles as C11 (no C++ in the boundary) and a C caller links the library"""
+    import subprocess
+    src = tmp_path / "c_caller.c"
+    src.write_text('#include "awry_hip.h"\n#include <stdio.h>\nint main(void) {\n  awry_index_t *ix = 0;\n'
+                   '  int rc = awry_load("/nonexistent.awry", &ix);\n  printf("%d %s\\n", rc, awry_last_error());\n'
+                   '  return rc == AWRY_ERR_IO && ix == 0 ? 0 : 1;\n}\n')
+    exe = tmp_path / "c_caller"
+    libdir = os.path.dirname(awry_amd.lib_path())
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["gcc", "-std=c11", "-Wall", "-Wextra", "-pedantic", "-I", os.path.join(root, "include"), str(src), "-o", str(exe),
+                           "-L", libdir, "-lawry_hip", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0, (r.stdout, r.stderr)

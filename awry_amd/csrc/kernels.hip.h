@@ -1269,20 +1269,38 @@ __global__ __launch_bounds__(256) void pack_nt2_tile_kernel(const uint8_t* __res
       const int m = fm == ~0ull ? 64 : __builtin_ctzll(~fm);  // leading run of fitting lanes
       const bool mine = (uint64_t)lane >= done && (uint64_t)lane < done + (m ? m : 1);
       auto pack_from = [&](auto src) {  // src: this lane's query bytes, in LDS or in global memory
+        // eight letters per step, word-wise: upper-case, check that every byte is one of A C G T, take bits 1..2 of the
+        // ASCII code (A 00, C 01, T 10, G 11), swap the last two, squeeze the eight 2-bit codes into 16 bits
         const int len = (int)(e - s);
         uint64_t w = 0;
-        bool ok = true;
+        uint64_t ok = 0x8080808080808080ull;  // bit 7 of byte b stays set while letter b of every step was valid
         uint64_t* out = words + q * (uint64_t)W;
-        for (int j = 0; j < len; j++) {
-          const uint8_t raw = src[j], a = raw & 0xDF;  // upper-case
-          const uint32_t c = a == 'A' ? 0u : (a == 'C' ? 1u : (a == 'G' ? 2u : (a == 'T' ? 3u : 4u)));
-          ok = ok && c < 4u && raw < 0x80;
-          w |= (uint64_t)(c & 3u) << (2 * (j & 31));
-          if ((j & 31) == 31 || j == len - 1) { out[j >> 5] = w; w = 0; }
+        constexpr uint64_t K7F = 0x7F7F7F7F7F7F7F7Full, K80 = 0x8080808080808080ull;
+        auto eq = [&](uint64_t u, uint64_t pat) { const uint64_t t = u ^ pat; return ((((t & K7F) + K7F) | t) & K80) ^ K80; };
+        for (int j = 0; j < len; j += 8) {
+          const int nb = len - j < 8 ? len - j : 8;
+          uint64_t x = 0;
+          if (nb == 8) {
+            __builtin_memcpy(&x, &src[j], 8);
+          } else {
+            for (int t = 0; t < nb; t++) x |= (uint64_t)src[j + t] << (8 * t);
+            x |= 0x4141414141414141ull << (8 * nb);  // pad with 'A': valid, and zero bits in the packed word
+          }
+          const uint64_t c = x & 0xDFDFDFDFDFDFDFDFull;  // upper-case
+          const uint64_t valid = (eq(c, 0x4141414141414141ull) | eq(c, 0x4343434343434343ull) | eq(c, 0x4747474747474747ull) |
+                                  eq(c, 0x5454545454545454ull)) & ~(x & K80);  // and no byte >= 0x80 before the case fold
+          ok &= valid;
+          uint64_t y = (c >> 1) & 0x0303030303030303ull;
+          y ^= (y >> 1) & 0x0101010101010101ull;
+          y = (y | (y >> 6)) & 0x000F000F000F000Full;
+          y = (y | (y >> 12)) & 0x000000FF000000FFull;
+          y = (y | (y >> 24)) & 0xFFFFull;
+          w |= y << (2 * (j & 31));
+          if ((j & 31) == 24 || j + 8 >= len) { out[j >> 5] = w; w = 0; }
         }
         for (int k2 = (len + 31) >> 5; k2 < W; k2++) out[k2] = 0;
         if (RAGGED) lens[q] = (uint32_t)len;
-        if (!ok) {  // rare: the caller redoes this query with the generic kernel
+        if (ok != K80) {  // rare: the caller redoes this query with the generic kernel
           const unsigned long long at = atomicAdd(bad, 1ull);
           if (bad_list) bad_list[at] = (uint32_t)q;
         }

@@ -80,23 +80,6 @@ struct DevBuf {  // RAII device allocation on the current device
   void reset() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
 };
 
-// one pipeline lane of the packed host path (count_shard_packed): buffers persist in the replica and only grow
-struct PackedLane {
-  hipStream_t s = nullptr;  // owned by the replica
-  hipEvent_t done = nullptr;
-  DevBuf<uint8_t> ascii;
-  DevBuf<uint64_t> words, counts, off;  // off / lens: batches of unequal lengths
-  DevBuf<uint32_t> lens, bad_list;      // bad_list: the chunk's queries with bytes outside ACGT
-  DevBuf<unsigned long long> bad;
-  unsigned long long* h_bad = nullptr;  // pinned
-  uint64_t chunk_lo = 0, chunk_hi = 0;
-  bool busy = false;
-  ~PackedLane() {
-    if (done) (void)hipEventDestroy(done);
-    if (h_bad) (void)hipHostFree(h_bad);
-  }
-};
-
 template <class T>
 struct PinBuf {  // pinned host staging, grows on demand
   T* p = nullptr;
@@ -114,6 +97,25 @@ struct PinBuf {  // pinned host staging, grows on demand
     hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&p), c * sizeof(T), hipHostMallocDefault);
     if (e != hipSuccess) { p = nullptr; throw HipError(std::string("hipHostMalloc failed: ") + hipGetErrorString(e)); }
     cap = c;
+  }
+};
+
+// one pipeline lane of the packed host path (count_shard_packed): buffers persist in the replica and only grow
+struct PackedLane {
+  hipStream_t s = nullptr;  // owned by the replica
+  hipEvent_t done = nullptr;
+  DevBuf<uint8_t> ascii;
+  DevBuf<uint64_t> words, counts, off;  // off / lens: batches of unequal lengths
+  DevBuf<uint32_t> lens, bad_list;      // bad_list: the chunk's queries with bytes outside ACGT
+  DevBuf<uint8_t> status;               // generic kernel: per-query status of the chunk,
+  PinBuf<uint8_t> h_status;             //   and where the host reads it
+  DevBuf<unsigned long long> bad;
+  unsigned long long* h_bad = nullptr;  // pinned
+  uint64_t chunk_lo = 0, chunk_hi = 0;
+  bool busy = false;
+  ~PackedLane() {
+    if (done) (void)hipEventDestroy(done);
+    if (h_bad) (void)hipHostFree(h_bad);
   }
 };
 
@@ -962,6 +964,79 @@ void count_shard_packed(Replica& r, const uint8_t* qbytes, const uint64_t* qoff,
   }
 }
 
+// Generic kernel, pipelined like the packed path: any alphabet, any letters, any lengths (amino batches, long or very
+// unequal nucleotide reads).  Pinned input / offsets / output, two stream lanes, persistent lane buffers; the kernel
+// reads the chunk's queries through the batch's own offsets (the ASCII pointer is biased by the chunk's first byte).
+void count_shard_generic_pipelined(Replica& r, const uint8_t* qbytes, const uint64_t* qoff, Shard sh, uint64_t* counts_out) {
+  for (uint64_t i = sh.lo; i < sh.hi; i++)  // (vectorises) non-decreasing offsets
+    if (qoff[i + 1] < qoff[i]) throw ArgError("query offsets must be non-decreasing");
+  const std::vector<Shard> chunks = packed_chunks(qoff, sh, 4u << 20, 256ull << 20);
+  uint64_t cap_q = 0, cap_b = 0;
+  for (Shard c : chunks) { cap_q = std::max(cap_q, c.hi - c.lo); cap_b = std::max(cap_b, qoff[c.hi] - qoff[c.lo]); }
+  std::lock_guard<std::mutex> lane_lock(r.lane_mu);
+  std::unique_ptr<HostPin> pin_out;
+  std::thread pin_out_thread([&] {
+    (void)hipSetDevice(r.device);
+    pin_out.reset(new HostPin(counts_out + sh.lo, (sh.hi - sh.lo) * 8));
+  });
+  struct Joiner {
+    std::thread& t;
+    ~Joiner() { if (t.joinable()) t.join(); }
+  } joiner{pin_out_thread};
+  HostPin pin_in(qbytes + qoff[sh.lo], qoff[sh.hi] - qoff[sh.lo]), pin_off(qoff + sh.lo, (sh.hi - sh.lo + 1) * 8);
+  PackedLane* lanes = r.lanes;
+  auto retire = [&](PackedLane& ln) {
+    if (!ln.busy) return;
+    ln.busy = false;
+    HIP_CHECK(hipEventSynchronize(ln.done));
+    const uint64_t n = ln.chunk_hi - ln.chunk_lo;
+    const uint8_t* st = ln.h_status.p;
+    uint64_t any = 0;
+    for (uint64_t i = 0; i < n; i++) any |= st[i];
+    if (any) {
+      ChunkBuffers cb;
+      cb.h_status.assign(st, st + n);
+      check_status(cb, ln.chunk_lo);  // raises INVALID_QUERY naming the first such query
+    }
+  };
+  struct Drain {
+    Replica& r;
+    ~Drain() {
+      for (int li = 0; li < 2; li++)
+        if (r.lanes[li].busy) { (void)hipStreamSynchronize(r.lane_stream[li]); r.lanes[li].busy = false; }
+    }
+  } drain{r};
+  for (int li = 0; li < 2; li++) {
+    PackedLane& ln = lanes[li];
+    ln.s = r.lane_stream[li];
+    if (!ln.done) HIP_CHECK(hipEventCreateWithFlags(&ln.done, hipEventDisableTiming));
+    if (ln.ascii.n < cap_b + 16) ln.ascii.alloc(cap_b + 16);
+    if (ln.off.n < cap_q + 1) ln.off.alloc(cap_q + 1);
+    if (ln.counts.n < cap_q) ln.counts.alloc(cap_q);
+    if (ln.status.n < cap_q) ln.status.alloc(cap_q);
+    ln.h_status.ensure(cap_q);
+  }
+  int which = 0;
+  for (Shard c : chunks) {
+    PackedLane& ln = lanes[which];
+    which ^= 1;
+    retire(ln);
+    const uint64_t lo = c.lo, hi = c.hi, n = hi - lo, base = qoff[lo], nbytes = qoff[hi] - base;
+    ln.chunk_lo = lo;
+    ln.chunk_hi = hi;
+    if (nbytes) HIP_CHECK(hipMemcpyAsync(ln.ascii.p, qbytes + base, nbytes, hipMemcpyHostToDevice, ln.s));
+    HIP_CHECK(hipMemcpyAsync(ln.off.p, qoff + lo, (n + 1) * 8, hipMemcpyHostToDevice, ln.s));
+    const uint8_t* biased = reinterpret_cast<const uint8_t*>(reinterpret_cast<uintptr_t>(ln.ascii.p) - base);
+    launch_count_ascii(r, biased, ln.off.p, n, ln.counts.p, nullptr, ln.status.p, ln.s, true);
+    if (pin_out_thread.joinable()) pin_out_thread.join();
+    HIP_CHECK(hipMemcpyAsync(counts_out + lo, ln.counts.p, n * 8, hipMemcpyDeviceToHost, ln.s));
+    HIP_CHECK(hipMemcpyAsync(ln.h_status.p, ln.status.p, n, hipMemcpyDeviceToHost, ln.s));
+    HIP_CHECK(hipEventRecord(ln.done, ln.s));
+    ln.busy = true;
+  }
+  for (int li = 0; li < 2; li++) retire(lanes[li]);
+}
+
 void count_shard(Replica& r, const uint8_t* qbytes, const uint64_t* qoff, Shard sh, uint64_t* counts_out) {
   HIP_CHECK(hipSetDevice(r.device));
   static const bool no_fast = getenv("AWRY_HOST_PATH") && !strcmp(getenv("AWRY_HOST_PATH"), "generic");
@@ -974,7 +1049,8 @@ void count_shard(Replica& r, const uint8_t* qbytes, const uint64_t* qoff, Shard 
     count_shard_packed(r, qbytes, qoff, sh, plan, counts_out);
     return;
   }
-  count_shard_generic(r, qbytes, qoff, sh, counts_out);
+  if (!no_fast && sh.hi - sh.lo >= 4096) count_shard_generic_pipelined(r, qbytes, qoff, sh, counts_out);
+  else count_shard_generic(r, qbytes, qoff, sh, counts_out);
 }
 
 void count_shard_generic(Replica& r, const uint8_t* qbytes, const uint64_t* qoff, Shard sh, uint64_t* counts_out, const uint64_t* names) {

@@ -276,6 +276,37 @@ def test_host_batch_fast_path_equals_generic(oracle, L, monkeypatch):
     assert e.value.code == ERR_INVALID_QUERY
 
 
+@pytest.mark.parametrize("alphabet", [0, 1])
+def test_generic_host_pipeline(oracle, alphabet):
+    """batches the packed kernels do not take -- amino queries, nucleotide batches of very unequal lengths -- go through
+    the generic kernel in the same pinned two-lane pipeline: the oracle's counts, undefined queries named by their index"""
+    text, st, hd = synth.make_text(200000, alphabet, 17 + alphabet, 3, 0.02 if alphabet == 0 else 0.0)
+    ix = gpu_index(text, alphabet, 8, 0, st, hd)
+    oi = oracle.OracleIndex.from_text(text, alphabet, 8, 0, st, hd)
+    rng = np.random.default_rng(alphabet)
+    nq = 30000
+    lens = rng.integers(1, 24, size=nq)
+    lens[::500] = rng.integers(600, 900, size=len(lens[::500]))  # a few long ones: no packed plan for this batch
+    qo = np.zeros(nq + 1, dtype=np.uint64)
+    qo[1:] = np.cumsum(lens)
+    starts = rng.integers(0, len(text) - 1000, size=nq)
+    idx = np.repeat(starts, lens) + (np.arange(int(qo[-1])) - np.repeat(qo[:-1].astype(np.int64), lens))
+    qb = text[idx].copy()
+    letters = synth.NT if alphabet == 0 else synth.AA
+    rmask = np.repeat(rng.random(nq) < 0.4, lens)
+    qb[rmask] = letters[rng.integers(0, len(letters), size=int(rmask.sum()))]
+    qb[qb == ord("$")] = letters[0]
+    low = np.repeat(rng.random(nq) < 0.1, lens)
+    qb[low] = np.frombuffer(bytes(qb[low]).lower(), dtype=np.uint8)
+    want, _ = oi.parallel_count(qb, qo, 4)
+    assert np.array_equal(ix.parallel_count_csr(qb, qo), want)
+    bad = qb.copy()
+    bad[int(qo[12345])] = ord("#")
+    with pytest.raises(AwryError) as e:
+        ix.parallel_count_csr(bad, qo)
+    assert e.value.code == ERR_INVALID_QUERY and "query 12345" in str(e.value)
+
+
 def test_packed_kmer_host_entry_point(oracle):
     """awry_count_packed_kmers: k-mers the caller already holds 2 bits per letter -- the ASCII entry point's counts"""
     text, st, hd = synth.make_text(300000, 0, 4, 2, 0.02)

@@ -21,3 +21,9 @@ for name, q2d in (("random", synth.random_queries(nq, L, 1, 3)), ("present", syn
     b.record(); torch.cuda.synchronize()
     ms = a.elapsed_time(b) / 3
     print("amino %s %d-mers: %.2f ms per %d queries -> %.2f G queries/s; mean count %.3f" % (name, L, ms, m, m / ms / 1e6, float(d_c.float().mean())), flush=True)
+# the host boundary: ASCII 12-mers in host memory -> counts in host memory (PCIe-inclusive)
+q2d = synth.random_queries(nq, L, 1, 3)
+qb, qo = synth.fixed_to_csr(q2d)
+for rep in range(3):
+    t = time.perf_counter(); c = ix.parallel_count_csr(qb, qo); dt = time.perf_counter() - t
+print("amino host boundary: %d %d-mers in %.1f ms -> %.1f M queries/s end-to-end" % (nq, L, dt * 1e3, nq / dt / 1e6), flush=True)

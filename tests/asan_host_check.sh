@@ -1,7 +1,7 @@
 #!/bin/bash
 # AddressSanitizer + UBSan over the host-side code paths that need no GPU (GPU ASan is not available on the pool):
 # the oracle (index build, search, locate, save/load) and the product's host index code (FASTA reader, SA-IS,
-# device-layout packing, .awry reader, layout round trips).  usage: tools/asan_host_check.sh
+# device-layout packing, .awry reader, layout round trips).  usage: tests/asan_host_check.sh
 set -euo pipefail
 cd "$(dirname "$0")/.."
 T=$(mktemp -d)

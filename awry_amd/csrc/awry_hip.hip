@@ -125,6 +125,8 @@ struct LocateLane {
   DevBuf<uint8_t> ascii;
   DevBuf<uint64_t> words, rstart, counts, hit_off, scratch, gpos, pos, off;
   DevBuf<uint32_t> lens, bad_list;
+  DevBuf<uint8_t> status;                      // generic kernel: per-query status of the chunk,
+  PinBuf<uint8_t> h_status;                    //   and where the host reads it
   std::vector<uint32_t> h_list;                // sorted chunk-relative indices of the queries redone by the generic kernels
   std::vector<uint64_t> sub_counts;            //   and their hit counts
   bool merge = false;                          // some of them have hits: stage 3 interleaves the two result sets
@@ -1164,7 +1166,16 @@ void locate_shard_generic(Replica& r, const uint8_t* qbytes, const uint64_t* qof
 // (2) once the host knows the chunk's hit total: locate kernels, D2H of the positions into pinned staging; (3) copy
 // into the result arrays -- so that one chunk's transfers and host copies overlap the other chunk's kernels.  A chunk
 // that holds bytes outside ACGT is redone by the generic kernels; results never depend on the path.
+// plan.ok == false: the same pipeline around the generic kernel (any alphabet, letters and lengths; ranges as two words
+// per query, statuses checked in stage 2)
 void locate_shard_packed(Replica& r, const uint8_t* qbytes, const uint64_t* qoff, Shard sh, PackedPlan plan, bool want_gpos, LocateResult& out) {
+  const bool generic = !plan.ok;
+  if (generic) {
+    plan.ragged = true;  // offsets travel with the chunk
+    plan.Lmax = 1;
+    for (uint64_t i = sh.lo; i < sh.hi; i++)
+      if (qoff[i + 1] < qoff[i]) throw ArgError("query offsets must be non-decreasing");
+  }
   const uint64_t L = plan.Lmax, W = (L + 31) / 32;
   const std::vector<Shard> chunks = packed_chunks(qoff, sh, 1u << 20, 128ull << 20);
   uint64_t cap = 0, cap_b = 0;
@@ -1193,7 +1204,9 @@ void locate_shard_packed(Replica& r, const uint8_t* qbytes, const uint64_t* qoff
     if (plan.ragged && ln.off.n < cap + 1) ln.off.alloc(cap + 1);
     if (plan.ragged && ln.lens.n < cap) ln.lens.alloc(cap);
     if (ln.bad_list.n < cap) ln.bad_list.alloc(cap);
-    if (ln.rstart.n < cap) ln.rstart.alloc(cap);
+    if (ln.rstart.n < (generic ? 2 : 1) * cap) ln.rstart.alloc((generic ? 2 : 1) * cap);
+    if (generic && ln.status.n < cap) ln.status.alloc(cap);
+    if (generic) ln.h_status.ensure(cap);
     if (ln.counts.n < cap) ln.counts.alloc(cap);
     if (ln.hit_off.n < cap + 1) ln.hit_off.alloc(cap + 1);
     if (ln.scratch.n < scan_tiles(cap) + 1) ln.scratch.alloc(scan_tiles(cap) + 1);
@@ -1215,12 +1228,18 @@ void locate_shard_packed(Replica& r, const uint8_t* qbytes, const uint64_t* qoff
     HIP_CHECK(hipMemcpyAsync(ln.ascii.p, qbytes + qoff[lo], nbytes, hipMemcpyHostToDevice, s));
     if (plan.ragged) HIP_CHECK(hipMemcpyAsync(ln.off.p, qoff + lo, (n + 1) * 8, hipMemcpyHostToDevice, s));
     HIP_CHECK(hipMemsetAsync(ln.bad.p, 0, 8, s));
-    launch_pack_nt2(r, ln.ascii.p, plan.ragged ? ln.off.p : nullptr, qoff[lo], n, nbytes, (int)L, (int)W, ln.words.p,
-                    plan.ragged ? ln.lens.p : nullptr, ln.bad.p, s, ln.bad_list.p);
-    launch_count_nt2_long(r, ln.words.p, n, (int)L, ln.counts.p, ln.rstart.p, true, s, plan.ragged ? ln.lens.p : nullptr);
-    // reads with other bytes count as "no hits" in this pass; stage 2 redoes them with the generic kernels
-    hipLaunchKernelGGL(zero_listed_counts_kernel, dim3(64), dim3(256), 0, s, ln.bad_list.p, ln.bad.p, ln.counts.p);
-    HIP_CHECK(hipGetLastError());
+    if (generic) {
+      const uint8_t* biased = reinterpret_cast<const uint8_t*>(reinterpret_cast<uintptr_t>(ln.ascii.p) - qoff[lo]);
+      launch_count_ascii(r, biased, ln.off.p, n, ln.counts.p, ln.rstart.p, ln.status.p, s, true);
+      HIP_CHECK(hipMemcpyAsync(ln.h_status.p, ln.status.p, n, hipMemcpyDeviceToHost, s));
+    } else {
+      launch_pack_nt2(r, ln.ascii.p, plan.ragged ? ln.off.p : nullptr, qoff[lo], n, nbytes, (int)L, (int)W, ln.words.p,
+                      plan.ragged ? ln.lens.p : nullptr, ln.bad.p, s, ln.bad_list.p);
+      launch_count_nt2_long(r, ln.words.p, n, (int)L, ln.counts.p, ln.rstart.p, true, s, plan.ragged ? ln.lens.p : nullptr);
+      // reads with other bytes count as "no hits" in this pass; stage 2 redoes them with the generic kernels
+      hipLaunchKernelGGL(zero_listed_counts_kernel, dim3(64), dim3(256), 0, s, ln.bad_list.p, ln.bad.p, ln.counts.p);
+      HIP_CHECK(hipGetLastError());
+    }
     launch_scan(r, ln.counts.p, n, ln.hit_off.p, ln.scratch.p, s);
     HIP_CHECK(hipMemcpyAsync(ln.h_meta.p, ln.hit_off.p + n, 8, hipMemcpyDeviceToHost, s));
     HIP_CHECK(hipMemcpyAsync(ln.h_meta.p + 1, ln.bad.p, 8, hipMemcpyDeviceToHost, s));
@@ -1234,7 +1253,16 @@ void locate_shard_packed(Replica& r, const uint8_t* qbytes, const uint64_t* qoff
     hipStream_t s = r.lane_stream[li];
     const uint64_t n = ln.hi - ln.lo;
     HIP_CHECK(hipEventSynchronize(ln.counted));
-    const uint64_t nb = ln.h_meta.p[1];
+    if (generic) {
+      uint64_t any = 0;
+      for (uint64_t i = 0; i < n; i++) any |= ln.h_status.p[i];
+      if (any) {
+        ChunkBuffers cb;
+        cb.h_status.assign(ln.h_status.p, ln.h_status.p + n);
+        check_status(cb, ln.lo);  // raises INVALID_QUERY naming the first such query
+      }
+    }
+    const uint64_t nb = generic ? 0 : ln.h_meta.p[1];
     if (nb && nb <= n / 8) {  // a few reads with other bytes (N, IUPAC codes ...): the generic kernels redo just those
       ln.h_list.resize(nb);
       HIP_CHECK(hipMemcpy(ln.h_list.data(), ln.bad_list.p, nb * 4, hipMemcpyDeviceToHost));  // final: the lane's stream is idle
@@ -1260,7 +1288,7 @@ void locate_shard_packed(Replica& r, const uint8_t* qbytes, const uint64_t* qoff
       if (ln.pos.n < 2 * ln.total) ln.pos.alloc(2 * (ln.total + ln.total / 4));
       ln.h_pos.ensure(ln.total);
       if (want_gpos) ln.h_gpos.ensure(ln.total);
-      launch_locate(r, ln.rstart.p, 1, ln.hit_off.p, n, ln.total, ln.gpos.p, ln.pos.p, s);
+      launch_locate(r, ln.rstart.p, generic ? 2 : 1, ln.hit_off.p, n, ln.total, ln.gpos.p, ln.pos.p, s);
       HIP_CHECK(hipMemcpyAsync(ln.h_pos.p, ln.pos.p, ln.total * 16, hipMemcpyDeviceToHost, s));
       if (want_gpos) HIP_CHECK(hipMemcpyAsync(ln.h_gpos.p, ln.gpos.p, ln.total * 8, hipMemcpyDeviceToHost, s));
     }
@@ -1319,7 +1347,7 @@ void locate_shard(Replica& r, const uint8_t* qbytes, const uint64_t* qoff, Shard
   static const bool no_fast = getenv("AWRY_HOST_PATH") && !strcmp(getenv("AWRY_HOST_PATH"), "generic");
   PackedPlan plan;
   if (!no_fast && r.dev.alphabet == NUCLEOTIDE && r.dev.bwt_len < (1ull << 32) - 512) plan = plan_packed(qoff, sh);
-  if (plan.ok)
+  if (plan.ok || (!no_fast && sh.hi - sh.lo >= 4096))
     locate_shard_packed(r, qbytes, qoff, sh, plan, want_gpos, out);
   else
     locate_shard_generic(r, qbytes, qoff, sh, want_gpos, out);

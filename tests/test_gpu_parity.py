@@ -298,13 +298,18 @@ def test_generic_host_pipeline(oracle, alphabet):
     qb[qb == ord("$")] = letters[0]
     low = np.repeat(rng.random(nq) < 0.1, lens)
     qb[low] = np.frombuffer(bytes(qb[low]).lower(), dtype=np.uint8)
-    want, _ = oi.parallel_count(qb, qo, 4)
-    assert np.array_equal(ix.parallel_count_csr(qb, qo), want)
+    ooff, ogpos, opos, _ = oi.parallel_locate(qb, qo, 4)
+    assert np.array_equal(ix.parallel_count_csr(qb, qo), np.diff(ooff))
+    for verify in (2, -1):
+        ix.set_verify(verify)
+        off, g, p = ix.parallel_locate_csr(qb, qo)
+        assert np.array_equal(off, ooff) and np.array_equal(g, ogpos) and np.array_equal(p, opos), verify
     bad = qb.copy()
     bad[int(qo[12345])] = ord("#")
-    with pytest.raises(AwryError) as e:
-        ix.parallel_count_csr(bad, qo)
-    assert e.value.code == ERR_INVALID_QUERY and "query 12345" in str(e.value)
+    for fn in (ix.parallel_count_csr, ix.parallel_locate_csr):
+        with pytest.raises(AwryError) as e:
+            fn(bad, qo)
+        assert e.value.code == ERR_INVALID_QUERY and "query 12345" in str(e.value)
 
 
 def test_packed_kmer_host_entry_point(oracle):

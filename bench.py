@@ -63,6 +63,34 @@ def unpack_nt2(words, L):
     return out
 
 
+def amino_benchmark(torch, dev, stream, n_text=90_000_000, nq=10_000_000, L=12):
+    """BASELINE.json configs[3]: Swiss-Prot-scale amino index (5-bit alphabet), 10 M 12-mers, count -- the generic
+    one-query-per-lane kernel with the 20^k seed table and the byte-text verify.  Device-resident ASCII, HIP events."""
+    import awry_amd
+    from tests import synth
+    text, st, hd = synth.make_text(n_text, 1, 0xA5A50004, 250_000, 0.0)
+    ix = awry_amd.FmIndex.from_text(text, 1, 8, 0, st, hd, build_device=dev.index).set_devices([dev.index])
+    out = {"text_len": n_text, "records": len(st), "query_len": L, "seed_k": ix.seed_kmer_len()}
+    for name, q2d in (("random", synth.random_queries(nq, L, 1, 3)), ("present", synth.sampled_queries(text, nq // 4, L, 4, False, 1))):
+        m = len(q2d)
+        d_q = torch.from_numpy(q2d.reshape(-1)).to(dev)
+        d_off = torch.arange(m + 1, dtype=torch.int64, device=dev) * L
+        d_c = torch.zeros(m, dtype=torch.int64, device=dev)
+        for _ in range(2):
+            ix.dev_count_ascii(d_q.data_ptr(), d_off.data_ptr(), m, d_c.data_ptr(), None, None, stream, 0)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(3):
+            ix.dev_count_ascii(d_q.data_ptr(), d_off.data_ptr(), m, d_c.data_ptr(), None, None, stream, 0)
+        b.record()
+        torch.cuda.synchronize()
+        ms = a.elapsed_time(b) / 3
+        if name == "present":
+            assert bool((d_c >= 1).all()), "a 12-mer sampled from the text was not found"
+        out[name] = {"queries": m, "queries_per_s": m / (ms * 1e-3), "kernel_ms": ms}
+    return out
+
+
 def locate_benchmark(ix, text, torch, dev, stream, n_reads, read_len, oi=None, cores=1):
     """SA-locate hits/s (BASELINE.json's second metric; configs[2] shape: reads sampled from the text, exact match).
     Pipeline on the device: packed reads -> seeded quad count (+range starts) -> scan -> tile locate.  Timed per phase
@@ -459,6 +487,10 @@ def main():
             del batches
             torch.cuda.empty_cache()
             result["locate"] = locate_benchmark(ix, text, torch, dev, stream, args.locate_reads, 101, oi, cores)
+            if args.workload == "grch38":
+                del ix
+                torch.cuda.empty_cache()
+                result["amino"] = amino_benchmark(torch, dev, stream)
 
     if world > 1:
         # parity re-checked at every G, outside the timed region.  All ranks count one common batch (half

@@ -1662,6 +1662,14 @@ __device__ __forceinline__ void localise(const DevIndex& ix, uint64_t g, uint64_
   out[0] = a;
   out[1] = g - (ix.nseq ? ix.seq_starts[a] : 0);
 }
+// the same over a copy of the record starts in LDS (a block loads it once): the search is a chain of dependent loads
+constexpr int LOC_SEQ_LDS = 1024;
+__device__ __forceinline__ void localise_lds(const uint64_t* s_starts, uint64_t nseq, uint64_t g, uint64_t* __restrict__ out) {
+  uint64_t a = 0, z = nseq;
+  while (z - a > 1) { uint64_t mid = (a + z) >> 1; if (s_starts[mid] <= g) a = mid; else z = mid; }
+  out[0] = a;
+  out[1] = g - (nseq ? s_starts[a] : 0);
+}
 
 // row -> "is it a sampled row" / sample index, without a 64-bit division per backstep (the test runs once per LF step;
 // a generic u64 modulo is ~100 instructions and made the walk ALU-bound): power-of-two ratios (the default 8) use a
@@ -1746,9 +1754,13 @@ __global__ __launch_bounds__(256) void locate_tile_kernel(DevIndex ix, const uin
                                                           unsigned long long* __restrict__ tile_counter) {
   __shared__ uint64_t s_off[LOC_QCAP + 1];
   __shared__ uint64_t s_sp[LOC_QCAP];
+  __shared__ uint64_t s_starts[LOC_SEQ_LDS];
   __shared__ unsigned long long s_tile;
   __shared__ uint64_t s_q[2];
   __shared__ int s_cursor;
+  const bool seq_lds = pos && ix.nseq <= (uint64_t)LOC_SEQ_LDS;
+  if (seq_lds)
+    for (uint64_t t = threadIdx.x; t < ix.nseq; t += blockDim.x) s_starts[t] = ix.seq_starts[t];
   const uint64_t ntiles = (total + LOC_TILE - 1) / LOC_TILE;
   for (;;) {
     if (threadIdx.x == 0) { s_tile = atomicAdd(tile_counter, 1ull); s_cursor = 0; }
@@ -1806,7 +1818,10 @@ __global__ __launch_bounds__(256) void locate_tile_kernel(DevIndex ix, const uin
       if (direct || row_is_sampled(ix, dense, dense_ratio, row)) {
         const uint64_t g = direct ? gd : walked_position(row_sample(ix, dense, dense_ratio, row), 0, ix.bwt_len);  // src/fm_index.rs:534, 0 steps
         gpos[h] = g;
-        if (pos) localise(ix, g, pos + 2 * h);
+        if (pos) {
+          if (seq_lds) localise_lds(s_starts, ix.nseq, g, pos + 2 * h);
+          else localise(ix, g, pos + 2 * h);
+        }
       } else {
         gpos[h] = row | LOC_WALK_FLAG;  // a walk kernel finishes this hit,
         if (pos) pos[2 * h] = ~0ull;    // localise_walked_kernel its record / offset

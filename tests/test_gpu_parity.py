@@ -168,6 +168,23 @@ def test_query_sharding_over_replicas_keeps_input_order(oracle):
     assert np.array_equal(one.parallel_count_csr(qb, qo), two.parallel_count_csr(qb, qo))
     a, b = one.parallel_locate_csr(qb, qo), two.parallel_locate_csr(qb, qo)
     assert all(np.array_equal(x, y) for x, y in zip(a, b))
+    # unequal lengths, a few reads with N, amino-free generic batches and packed words shard the same way
+    rng = np.random.default_rng(3)
+    lens = rng.integers(5, 60, size=9001)
+    ro = np.zeros(len(lens) + 1, dtype=np.uint64)
+    ro[1:] = np.cumsum(lens)
+    starts = rng.integers(0, len(text) - 70, size=len(lens))
+    rb = text[np.repeat(starts, lens) + (np.arange(int(ro[-1])) - np.repeat(ro[:-1].astype(np.int64), lens))].copy()
+    rb[rb == ord("$")] = ord("A")
+    assert np.array_equal(one.parallel_count_csr(rb, ro), two.parallel_count_csr(rb, ro))
+    a, b = one.parallel_locate_csr(rb, ro), two.parallel_locate_csr(rb, ro)
+    assert all(np.array_equal(x, y) for x, y in zip(a, b))
+    code = np.searchsorted(synth.NT, q2d).astype(np.uint64)
+    words = np.zeros(len(q2d), dtype=np.uint64)
+    for j in range(q2d.shape[1]):
+        words |= code[:, j] << np.uint64(2 * j)
+    assert np.array_equal(one.parallel_count_packed(words, 14), two.parallel_count_packed(words, 14))
+    assert np.array_equal(one.parallel_count_packed(words, 14), one.parallel_count_csr(qb, qo))
 
 
 def test_medium_scale_properties():

@@ -1283,6 +1283,25 @@ void locate_shard_packed(Replica& r, const uint8_t* qbytes, const uint64_t* qoff
     }
     out.add_counts(ln.h_counts.p, n);  // stage 2 runs in chunk order
     ln.total = ln.h_meta.p[0];
+    const uint64_t STAGE_CAP = 16ull << 20;  // hits the pinned staging of a lane holds at most (384 MB)
+    if (ln.total > STAGE_CAP && !ln.merge) {
+      // a hit-heavy chunk (repeats, N runs): the positions come back in pieces through the bounded staging, appended
+      // here -- every earlier chunk has been appended already (stage 3 of chunk i - 2 runs before stage 1 of chunk i)
+      if (ln.gpos.n < ln.total) ln.gpos.alloc(ln.total + ln.total / 4);
+      if (ln.pos.n < 2 * ln.total) ln.pos.alloc(2 * (ln.total + ln.total / 4));
+      ln.h_pos.ensure(STAGE_CAP);
+      if (want_gpos) ln.h_gpos.ensure(STAGE_CAP);
+      launch_locate(r, ln.rstart.p, generic ? 2 : 1, ln.hit_off.p, n, ln.total, ln.gpos.p, ln.pos.p, s);
+      for (uint64_t at = 0; at < ln.total; at += STAGE_CAP) {
+        const uint64_t m = std::min(STAGE_CAP, ln.total - at);
+        HIP_CHECK(hipMemcpyAsync(ln.h_pos.p, ln.pos.p + 2 * at, m * 16, hipMemcpyDeviceToHost, s));
+        if (want_gpos) HIP_CHECK(hipMemcpyAsync(ln.h_gpos.p, ln.gpos.p + at, m * 8, hipMemcpyDeviceToHost, s));
+        HIP_CHECK(hipStreamSynchronize(s));
+        out.append(ln.h_gpos.p, ln.h_pos.p, m, want_gpos);
+      }
+      ln.stage = 0;
+      return;
+    }
     if (ln.total) {
       if (ln.gpos.n < ln.total) ln.gpos.alloc(ln.total + ln.total / 4);
       if (ln.pos.n < 2 * ln.total) ln.pos.alloc(2 * (ln.total + ln.total / 4));
@@ -1333,8 +1352,8 @@ void locate_shard_packed(Replica& r, const uint8_t* qbytes, const uint64_t* qoff
     i++;
   }
   const int last = (int)((i + 1) & 1);            // lane of chunk i - 1
+  stage3(last ^ 1);                               // chunk i - 2 first: stage 2 may append a hit-heavy chunk itself
   stage2(last);
-  stage3(last ^ 1);
   stage3(last);
   if (trace)
     fprintf(stderr, "[awry] packed locate shard: %llu reads, %zu hits, %.2f ms\n", (unsigned long long)(sh.hi - sh.lo), out.total,

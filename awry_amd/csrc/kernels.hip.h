@@ -147,6 +147,39 @@ struct ByteStream {
   }
 };
 
+// Eight ASCII nucleotide letters -> eight symbol indices, word-wise (src/alphabet.rs:109-114,169-248: A 1, C 2, G 3,
+// T / U 5, everything else N = 4; '$' / '#' and bytes >= 0x80 never get here, their queries are rejected).
+__device__ __forceinline__ uint64_t nt_indices8(uint64_t x) {
+  constexpr uint64_t K7F = 0x7F7F7F7F7F7F7F7Full, K80 = 0x8080808080808080ull;
+  const uint64_t c = x & 0xDFDFDFDFDFDFDFDFull;  // upper-case
+  auto eq = [&](uint64_t pat) { const uint64_t t = c ^ pat; return (((((t & K7F) + K7F) | t) & K80) ^ K80) >> 7; };  // 1 per equal byte
+  const uint64_t a = eq(0x4141414141414141ull), cc = eq(0x4343434343434343ull), g = eq(0x4747474747474747ull),
+                 t = eq(0x5454545454545454ull) | eq(0x5555555555555555ull);
+  return 0x0404040404040404ull - 3 * a - 2 * cc - g + t;  // bytewise, no borrows: at most one of the masks is set per byte
+}
+
+// Do the `rem` symbols text8[0 .. rem) equal the query bytes q[0 .. rem) (as symbol indices)?  Nucleotide: eight at a
+// time; both buffers are readable 8 bytes past their end.
+template <int A>
+__device__ __forceinline__ bool text_equals_query(const uint8_t* __restrict__ text8, const uint8_t* __restrict__ q, uint64_t rem,
+                                                  const uint8_t* lut) {
+  if (A == NUCLEOTIDE) {
+    for (uint64_t j = 0; j < rem; j += 8) {
+      uint64_t tw, qw;
+      __builtin_memcpy(&tw, text8 + j, 8);
+      __builtin_memcpy(&qw, q + j, 8);
+      uint64_t d = tw ^ nt_indices8(qw);
+      if (rem - j < 8) d &= (1ull << (8 * (rem - j))) - 1;
+      if (d) return false;
+    }
+    return true;
+  }
+  ByteStream t(text8), a(q);
+  for (uint64_t j = 0; j < rem; j++)
+    if (t[j] != lut[a[j]]) return false;
+  return true;
+}
+
 // status[q] != 0 marks inputs the reference leaves undefined: empty query, '$'/'#',
 // bytes >= 0x80.  ranges (optional) receives the final (start, end) row interval.
 // allow_verify (with the dense SA and ix.text8 resident): once the range has shrunk to <= 4 rows, the letters still to
@@ -166,10 +199,25 @@ __global__ __launch_bounds__(256) void count_scalar_kernel(DevIndex ix, const ui
     const uint64_t b = off[q], e = off[q + 1];
     ByteStream ascii(ascii_bytes);  // shadows the pointer: same indexing, 8 bytes per load
     uint8_t st = e > b ? Q_OK : Q_EMPTY;
-    for (uint64_t i = b; i < e; i++) {
-      uint8_t s = lut[ascii[i]];
-      if (s == 0xFF) st = Q_NON_ASCII;
-      else if (s == 0 && st == Q_OK) st = Q_SENTINEL;
+    if (A == NUCLEOTIDE) {  // eight bytes at a time: any byte >= 0x80, any '$' or '#'
+      constexpr uint64_t K7F = 0x7F7F7F7F7F7F7F7Full, K80 = 0x8080808080808080ull;
+      uint64_t high = 0, sent = 0;
+      for (uint64_t i = b; i < e; i += 8) {
+        uint64_t x;
+        __builtin_memcpy(&x, ascii_bytes + i, 8);
+        if (e - i < 8) x &= (1ull << (8 * (e - i))) - 1;  // bytes past the query read as 0: neither test fires
+        high |= x & K80;
+        const uint64_t t1 = x ^ 0x2424242424242424ull, t2 = x ^ 0x2323232323232323ull;
+        sent |= (((((t1 & K7F) + K7F) | t1) & K80) ^ K80) | (((((t2 & K7F) + K7F) | t2) & K80) ^ K80);
+      }
+      if (high) st = Q_NON_ASCII;
+      else if (sent && st == Q_OK) st = Q_SENTINEL;
+    } else {
+      for (uint64_t i = b; i < e; i++) {
+        uint8_t s = lut[ascii[i]];
+        if (s == 0xFF) st = Q_NON_ASCII;
+        else if (s == 0 && st == Q_OK) st = Q_SENTINEL;
+      }
     }
     uint64_t sp = 1, ep = 0, vcount = 0, vrs = 0;
     bool verified = false;
@@ -192,9 +240,7 @@ __global__ __launch_bounds__(256) void count_scalar_kernel(DevIndex ix, const ui
           if (ix.seed_pos && scnt == 1 && !wrong_sym) {  // position seed, as in the nucleotide branch below
             const uint64_t rem = e - k - b, p = se.sp;
             if (allow_verify && ix.text8 && rem < 65536) {
-              bool same = p >= rem;
-              ByteStream t(ix.text8 + (p - rem));
-              for (uint64_t j = 0; j < rem && same; j++) same = t[j] == lut[ascii[b + j]];
+              const bool same = p >= rem && text_equals_query<A>(ix.text8 + (p - rem), ascii_bytes + b, rem, lut);
               verified = true;
               vcount = same ? 1 : 0;
               vrs = same ? ((RS_SINGLE << RS_MODE_SHIFT) | (p - rem)) : ((RS_MULTI << RS_MODE_SHIFT) | (rem << 32));
@@ -229,9 +275,8 @@ __global__ __launch_bounds__(256) void count_scalar_kernel(DevIndex ix, const ui
           if (ix.seed_pos && scnt == 1 && !wrong_sym) {
             const uint64_t rem = e - k - b, p = seed_position(se, (int)ix.ctx_extra);
             if (allow_verify && ix.text8 && rem < 65536) {
-              bool same = p >= rem;  // else the suffix starts too close to the text's beginning
-              ByteStream t(ix.text8 + (p - rem));
-              for (uint64_t j = 0; j < rem && same; j++) same = t[j] == lut[ascii[b + j]];
+              // (p < rem: the suffix starts too close to the text's beginning)
+              const bool same = p >= rem && text_equals_query<A>(ix.text8 + (p - rem), ascii_bytes + b, rem, lut);
               verified = true;
               vcount = same ? 1 : 0;
               vrs = same ? ((RS_SINGLE << RS_MODE_SHIFT) | (p - rem)) : ((RS_MULTI << RS_MODE_SHIFT) | (rem << 32));
@@ -261,10 +306,7 @@ __global__ __launch_bounds__(256) void count_scalar_kernel(DevIndex ix, const ui
           for (uint64_t c = 0; c < cnt; c++) {
             const uint64_t p = ix.dense_sa[sp + c];
             if (p < rem) continue;  // the suffix starts too close to the text's beginning
-            ByteStream t(ix.text8 + (p - rem));
-            bool same = true;
-            for (uint64_t j = 0; j < rem && same; j++) same = t[j] == lut[ascii[b + j]];
-            if (same) { mask |= 1u << c; g1 = p - rem; }
+            if (text_equals_query<A>(ix.text8 + (p - rem), ascii_bytes + b, rem, lut)) { mask |= 1u << c; g1 = p - rem; }
           }
           verified = true;
           vcount = (uint64_t)__popc(mask);

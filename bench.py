@@ -192,7 +192,7 @@ def main():
     ap.add_argument("--seed-k", type=int, default=-1, help="device seed-table k (-1 = library default, 0 = off)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline duration (0 = skip)")
     ap.add_argument("--no-variants", action="store_true")
-    ap.add_argument("--locate-reads", type=int, default=5_000_000, help="101-bp reads in the locate measurement (N=1)")
+    ap.add_argument("--locate-reads", type=int, default=20_000_000, help="101-bp reads in the locate measurement (N=1; BASELINE configs[2] has 100 M)")
     ap.add_argument("--sweep-seed-k", default="", help="comma list of seed k to time on rank 0 before the run (stderr)")
     args = ap.parse_args()
 

@@ -429,14 +429,48 @@ void launch_pack_nt2(Replica& r, const uint8_t* d_ascii, const uint64_t* d_off, 
 }
 
 // allow_verify: the generic kernel may finish queries against the text (ranges then hold RS_* words for locate, not rows)
+// ulen != 0: n queries of ulen bytes each, back to back (d_off is not read)
 void launch_count_ascii(Replica& r, const uint8_t* d_q, const uint64_t* d_off, uint64_t n, uint64_t* d_counts,
-                        uint64_t* d_ranges, uint8_t* d_status, hipStream_t s, bool allow_verify) {
+                        uint64_t* d_ranges, uint8_t* d_status, hipStream_t s, bool allow_verify, uint64_t ulen = 0) {
   if (n == 0) return;
   const dim3 g(grid_for(r, n, 256)), b(256);
+  const QueryList none{};
   if (r.dev.alphabet == NUCLEOTIDE)
-    hipLaunchKernelGGL(count_scalar_kernel<NUCLEOTIDE>, g, b, 0, s, r.dev, d_q, d_off, n, d_counts, d_ranges, d_status, allow_verify ? 1 : 0);
+    hipLaunchKernelGGL((count_scalar_kernel<NUCLEOTIDE, false>), g, b, 0, s, r.dev, d_q, d_off, n, d_counts, d_ranges, d_status, allow_verify ? 1 : 0, ulen, none);
   else
-    hipLaunchKernelGGL(count_scalar_kernel<AMINO>, g, b, 0, s, r.dev, d_q, d_off, n, d_counts, d_ranges, d_status, allow_verify ? 1 : 0);
+    hipLaunchKernelGGL((count_scalar_kernel<AMINO, false>), g, b, 0, s, r.dev, d_q, d_off, n, d_counts, d_ranges, d_status, allow_verify ? 1 : 0, ulen, none);
+  HIP_CHECK(hipGetLastError());
+}
+
+Replica::SurvScratch* surv_scratch(Replica& r, hipStream_t s);
+
+// n ASCII queries of L bytes each, back to back: counts (and status) only.  Amino k-mers with a seed table take the
+// two-phase schedule (count_aa_kmer_probe_kernel, then the generic kernel on what it listed); anything else is the
+// generic kernel reading its queries at q * L.
+void launch_count_ascii_uniform(Replica& r, const uint8_t* d_q, uint64_t n, uint64_t L, uint64_t* d_counts, uint8_t* d_status, hipStream_t s) {
+  if (n == 0) return;
+  require(L >= 1, "query length must be at least 1");
+  static const bool off = getenv("AWRY_AA_KMER") && !strcmp(getenv("AWRY_AA_KMER"), "0");
+  const bool two_phase = !off && r.dev.alphabet == AMINO && L >= (uint64_t)AA_KMER_MIN && L <= (uint64_t)AA_KMER_MAX && r.seed_k >= 1 &&
+                         (uint64_t)r.seed_k <= L && n < (1ull << 32);
+  if (!two_phase) {
+    launch_count_ascii(r, d_q, nullptr, n, d_counts, nullptr, d_status, s, true, L);
+    return;
+  }
+  Replica::SurvScratch* sc = surv_scratch(r, s);
+  const unsigned nblk = (unsigned)r.num_cus * 8;  // both phases use this grid
+  const uint64_t per_block = ((n + (uint64_t)nblk * 256 - 1) / ((uint64_t)nblk * 256)) * 256;  // queries a block sees
+  if (sc->cap_q < per_block * nblk) {
+    HIP_CHECK(hipStreamSynchronize(s));
+    sc->q.alloc(per_block * nblk);
+    sc->cap_q = per_block * nblk;
+    sc->cap = 0;  // the nucleotide k-mer path re-allocates its three lists together
+  }
+  if (!sc->count.p) sc->count.alloc(nblk);
+  const QueryList ql{sc->q.p, sc->count.p, per_block};
+  // two queries in flight per lane (one: the same rate; four: 141 VGPRs, 10 % slower)
+  hipLaunchKernelGGL(count_aa_kmer_probe_kernel<2>, dim3(nblk), dim3(256), 0, s, r.dev, d_q, n, (int)L, d_counts, d_status, ql);
+  hipLaunchKernelGGL((count_scalar_kernel<AMINO, true>), dim3(nblk), dim3(256), 0, s, r.dev, d_q, nullptr, n, d_counts, nullptr, d_status, 1, L, ql);
   HIP_CHECK(hipGetLastError());
 }
 
@@ -969,7 +1003,8 @@ void count_shard_packed(Replica& r, const uint8_t* qbytes, const uint64_t* qoff,
 // Generic kernel, pipelined like the packed path: any alphabet, any letters, any lengths (amino batches, long or very
 // unequal nucleotide reads).  Pinned input / offsets / output, two stream lanes, persistent lane buffers; the kernel
 // reads the chunk's queries through the batch's own offsets (the ASCII pointer is biased by the chunk's first byte).
-void count_shard_generic_pipelined(Replica& r, const uint8_t* qbytes, const uint64_t* qoff, Shard sh, uint64_t* counts_out) {
+// ulen != 0: every query of the shard has ulen bytes -- the offsets stay on the host and the kernels address query q at q * ulen.
+void count_shard_generic_pipelined(Replica& r, const uint8_t* qbytes, const uint64_t* qoff, Shard sh, uint64_t* counts_out, uint64_t ulen = 0) {
   for (uint64_t i = sh.lo; i < sh.hi; i++)  // (vectorises) non-decreasing offsets
     if (qoff[i + 1] < qoff[i]) throw ArgError("query offsets must be non-decreasing");
   const std::vector<Shard> chunks = packed_chunks(qoff, sh, 4u << 20, 256ull << 20);
@@ -985,7 +1020,7 @@ void count_shard_generic_pipelined(Replica& r, const uint8_t* qbytes, const uint
     std::thread& t;
     ~Joiner() { if (t.joinable()) t.join(); }
   } joiner{pin_out_thread};
-  HostPin pin_in(qbytes + qoff[sh.lo], qoff[sh.hi] - qoff[sh.lo]), pin_off(qoff + sh.lo, (sh.hi - sh.lo + 1) * 8);
+  HostPin pin_in(qbytes + qoff[sh.lo], qoff[sh.hi] - qoff[sh.lo]), pin_off(ulen ? nullptr : qoff + sh.lo, (sh.hi - sh.lo + 1) * 8);
   PackedLane* lanes = r.lanes;
   auto retire = [&](PackedLane& ln) {
     if (!ln.busy) return;
@@ -1013,7 +1048,7 @@ void count_shard_generic_pipelined(Replica& r, const uint8_t* qbytes, const uint
     ln.s = r.lane_stream[li];
     if (!ln.done) HIP_CHECK(hipEventCreateWithFlags(&ln.done, hipEventDisableTiming));
     if (ln.ascii.n < cap_b + 16) ln.ascii.alloc(cap_b + 16);
-    if (ln.off.n < cap_q + 1) ln.off.alloc(cap_q + 1);
+    if (!ulen && ln.off.n < cap_q + 1) ln.off.alloc(cap_q + 1);
     if (ln.counts.n < cap_q) ln.counts.alloc(cap_q);
     if (ln.status.n < cap_q) ln.status.alloc(cap_q);
     ln.h_status.ensure(cap_q);
@@ -1027,9 +1062,13 @@ void count_shard_generic_pipelined(Replica& r, const uint8_t* qbytes, const uint
     ln.chunk_lo = lo;
     ln.chunk_hi = hi;
     if (nbytes) HIP_CHECK(hipMemcpyAsync(ln.ascii.p, qbytes + base, nbytes, hipMemcpyHostToDevice, ln.s));
-    HIP_CHECK(hipMemcpyAsync(ln.off.p, qoff + lo, (n + 1) * 8, hipMemcpyHostToDevice, ln.s));
-    const uint8_t* biased = reinterpret_cast<const uint8_t*>(reinterpret_cast<uintptr_t>(ln.ascii.p) - base);
-    launch_count_ascii(r, biased, ln.off.p, n, ln.counts.p, nullptr, ln.status.p, ln.s, true);
+    if (ulen) {
+      launch_count_ascii_uniform(r, ln.ascii.p, n, ulen, ln.counts.p, ln.status.p, ln.s);
+    } else {
+      HIP_CHECK(hipMemcpyAsync(ln.off.p, qoff + lo, (n + 1) * 8, hipMemcpyHostToDevice, ln.s));
+      const uint8_t* biased = reinterpret_cast<const uint8_t*>(reinterpret_cast<uintptr_t>(ln.ascii.p) - base);
+      launch_count_ascii(r, biased, ln.off.p, n, ln.counts.p, nullptr, ln.status.p, ln.s, true);
+    }
     if (pin_out_thread.joinable()) pin_out_thread.join();
     HIP_CHECK(hipMemcpyAsync(counts_out + lo, ln.counts.p, n * 8, hipMemcpyDeviceToHost, ln.s));
     HIP_CHECK(hipMemcpyAsync(ln.h_status.p, ln.status.p, n, hipMemcpyDeviceToHost, ln.s));
@@ -1051,8 +1090,15 @@ void count_shard(Replica& r, const uint8_t* qbytes, const uint64_t* qoff, Shard 
     count_shard_packed(r, qbytes, qoff, sh, plan, counts_out);
     return;
   }
-  if (!no_fast && sh.hi - sh.lo >= 4096) count_shard_generic_pipelined(r, qbytes, qoff, sh, counts_out);
-  else count_shard_generic(r, qbytes, qoff, sh, counts_out);
+  if (!no_fast && sh.hi - sh.lo >= 4096) {
+    // amino batches of one length (k-mers): no offsets cross PCIe and the two-phase amino schedule serves them
+    uint64_t ulen = 0;
+    if (r.dev.alphabet == AMINO) {
+      const PackedPlan ap = plan_packed(qoff, sh);
+      if (ap.ok && !ap.ragged) ulen = ap.Lmax;
+    }
+    count_shard_generic_pipelined(r, qbytes, qoff, sh, counts_out, ulen);
+  } else count_shard_generic(r, qbytes, qoff, sh, counts_out);
 }
 
 void count_shard_generic(Replica& r, const uint8_t* qbytes, const uint64_t* qoff, Shard sh, uint64_t* counts_out, const uint64_t* names) {
@@ -1971,6 +2017,15 @@ int awry_dev_count_ascii(awry_index_t* idx, int slot, const void* d_qbytes, cons
     require((d_qoff && d_counts) || n == 0, "null device pointer");
     launch_count_ascii(r, (const uint8_t*)d_qbytes, (const uint64_t*)d_qoff, n, (uint64_t*)d_counts, (uint64_t*)d_ranges,
                        (uint8_t*)d_status, (hipStream_t)stream, d_ranges == nullptr);  // ranges requested: they are row intervals
+  });
+}
+
+int awry_dev_count_ascii_uniform(awry_index_t* idx, int slot, const void* d_qbytes, uint64_t n, uint64_t len, void* d_counts,
+                                 void* d_status, void* stream) {
+  return guarded([&] {
+    Replica& r = replica(idx, slot);
+    require((d_qbytes && d_counts) || n == 0, "null device pointer");
+    launch_count_ascii_uniform(r, (const uint8_t*)d_qbytes, n, len, (uint64_t*)d_counts, (uint8_t*)d_status, (hipStream_t)stream);
   });
 }
 

@@ -185,18 +185,28 @@ __device__ __forceinline__ bool text_equals_query(const uint8_t* __restrict__ te
 // allow_verify (with the dense SA and ix.text8 resident): once the range has shrunk to <= 4 rows, the letters still to
 // the left are compared with the text in front of each candidate instead of being stepped one by one; ranges[2q] then
 // holds an RS_SINGLE / RS_MULTI word for the locate pass, not a row interval -- callers that need rows pass 0.
-template <int A>
+// ulen != 0: every query has ulen bytes, back to back (off is not read).  LIST: only the queries block b of an earlier
+// pass (same grid) listed for itself, ql.q[b * ql.cap ...) -- the second phase of count_aa_kmer_probe_kernel.
+struct QueryList {
+  uint32_t* q;      // query indices, block b owns slots [b * cap, (b + 1) * cap)
+  uint32_t* count;  // listed queries per block
+  uint64_t cap;
+};
+
+template <int A, bool LIST = false>
 __global__ __launch_bounds__(256) void count_scalar_kernel(DevIndex ix, const uint8_t* __restrict__ ascii,
                                                            const uint64_t* __restrict__ off, uint64_t n,
                                                            uint64_t* __restrict__ counts, uint64_t* __restrict__ ranges,
-                                                           uint8_t* __restrict__ status, int allow_verify) {
+                                                           uint8_t* __restrict__ status, int allow_verify, uint64_t ulen, QueryList ql) {
   __shared__ uint8_t lut[256];
   lut[threadIdx.x] = (uint8_t)(threadIdx.x >= 128 ? 0xFF : index_of_ascii(A, (uint8_t)threadIdx.x));
   __syncthreads();
-  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  const uint64_t stride = LIST ? blockDim.x : (uint64_t)gridDim.x * blockDim.x;
+  const uint64_t todo = LIST ? ql.count[blockIdx.x] : n;
   const uint8_t* const ascii_bytes = ascii;
-  for (uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += stride) {
-    const uint64_t b = off[q], e = off[q + 1];
+  for (uint64_t it = LIST ? threadIdx.x : (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; it < todo; it += stride) {
+    const uint64_t q = LIST ? ql.q[(uint64_t)blockIdx.x * ql.cap + it] : it;
+    const uint64_t b = ulen ? q * ulen : off[q], e = ulen ? b + ulen : off[q + 1];
     ByteStream ascii(ascii_bytes);  // shadows the pointer: same indexing, 8 bytes per load
     uint8_t st = e > b ? Q_OK : Q_EMPTY;
     if (A == NUCLEOTIDE) {  // eight bytes at a time: any byte >= 0x80, any '$' or '#'
@@ -327,6 +337,172 @@ __global__ __launch_bounds__(256) void count_scalar_kernel(DevIndex ix, const ui
     }
     if (status) status[q] = st;
   }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Amino k-mer batches: n ASCII queries of the same length L (AA_KMER_MIN..AA_KMER_MAX residues) back to back -- the
+// shape of BASELINE configs[3] (10 M 12-mers).  First phase of a two-phase schedule, one query per LANE, NQ in flight:
+// the bytes of a query are two or three unaligned 8-byte loads at q * L (no offsets, no byte stream), an LDS table
+// turns each byte into its symbol index and its base-20 digit, the last k residues name one seed entry (the query's
+// one random line).  Entry empty: absent.  Singleton whose BWT symbol is not the next residue: absent.  Singleton
+// otherwise (position seeds, dense SA and byte text resident): the L - k residues in front of the one candidate are
+// one <= 24-B window of the text, compared word-wise; an entry of 2..AA_KMER_VMULTI rows likewise, candidate by
+// candidate through the dense SA, when enough lanes of the wave hold one.  Everything else -- a non-standard residue
+// in the seed window, bytes the reference leaves undefined, entries with more rows, row seeds -- is listed per block
+// and redone by count_scalar_kernel<AMINO, true> on the same grid.  The generic kernel spends ~1 900 wave instructions
+// per 64 such queries, most of them offset and byte-stream bookkeeping; this pass ~350.
+constexpr int AA_KMER_MIN = 8, AA_KMER_MAX = 24;
+constexpr int AA_KMER_VMULTI = 4;        // seed ranges of up to this many rows are verified candidate by candidate
+constexpr int AA_KMER_VMULTI_LANES = 8;  //   when at least this many lanes of the wave hold one
+
+template <int NQ>
+__global__ __launch_bounds__(256) void count_aa_kmer_probe_kernel(DevIndex ix, const uint8_t* __restrict__ ascii, uint64_t n, int L,
+                                                                  uint64_t* __restrict__ counts, uint8_t* __restrict__ status, QueryList ql) {
+  // per byte: bits 0..4 symbol index, bits 8..12 base-20 digit of a standard residue, bit 14 not a standard residue
+  // (X and every other letter search as X, index 20), bit 15 undefined in the reference ('$', '#', bytes >= 0x80)
+  __shared__ uint16_t lut[256];
+  __shared__ unsigned int s_count;
+  {
+    const int c = threadIdx.x;
+    const int idx = c >= 128 ? 0 : index_of_ascii(AMINO, (uint8_t)c);
+    const int digit = aa_letter_of_index(idx);
+    lut[c] = (uint16_t)(idx <= 0 ? 0x8000 : (idx | (digit < 0 ? 0x4000 : digit << 8)));
+  }
+  if (threadIdx.x == 0) s_count = 0;
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int k = ix.seed_k, rem = L - k;
+  const SeedEntry* __restrict__ seed = ix.seed;
+  const bool pos = ix.seed_pos && ix.text8 && ix.dense_sa && ix.dense_ratio == 1;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  const uint64_t lane_lt = (1ull << lane) - 1;
+  const uint64_t region = (uint64_t)blockIdx.x * ql.cap;
+  auto bytes_mask = [](int m) { return m >= 8 ? ~0ull : (m <= 0 ? 0ull : (1ull << (8 * m)) - 1); };
+  const uint64_t m0 = bytes_mask(rem), m1 = bytes_mask(rem - 8), m2 = bytes_mask(rem - 16);
+  auto ld8 = [](const uint8_t* p) { uint64_t v; __builtin_memcpy(&v, p, 8); return v; };
+  // how many of the candidates at text positions p[0 .. nc) have the query's first `rem` residues in front of them
+  auto candidates = [&](const uint32_t (&p)[AA_KMER_VMULTI], uint32_t nc, uint64_t j0, uint64_t j1, uint64_t j2) {
+    uint64_t found = 0;
+#pragma unroll
+    for (int c = 0; c < AA_KMER_VMULTI; c++) {
+      if ((uint32_t)c >= nc || p[c] < (uint32_t)rem) continue;  // (the suffix starts too close to the text's beginning)
+      const uint8_t* t = ix.text8 + ((uint64_t)p[c] - (uint64_t)rem);
+      uint64_t d = (ld8(t) ^ j0) & m0;
+      if (rem > 8) d |= (ld8(t + 8) ^ j1) & m1;
+      if (rem > 16) d |= (ld8(t + 16) ^ j2) & m2;
+      found += d ? 0ull : 1ull;
+    }
+    return found;
+  };
+  // the trip count is wave-uniform (ballots and the wave-level atomic below need every lane of the wave)
+  for (uint64_t wbase = (uint64_t)blockIdx.x * blockDim.x + (threadIdx.x & ~63u); wbase < n; wbase += NQ * stride) {
+    uint64_t qv[NQ], c0[NQ], c1[NQ], c2[NQ];
+#pragma unroll
+    for (int h = 0; h < NQ; h++) {  // bytes [0, 8), [8, 16), [16, 24) of the query, zero past its end
+      qv[h] = wbase + lane + (uint64_t)h * stride;
+      c0[h] = c1[h] = c2[h] = 0;
+      if (qv[h] < n) {
+        const uint8_t* p = ascii + qv[h] * (uint64_t)L;
+        c0[h] = ld8(p);
+        if (L > 8) {
+          const uint64_t last = ld8(p + L - 8);  // never reads past the query
+          if (L >= 16) { c1[h] = ld8(p + 8); if (L > 16) c2[h] = last >> (8 * (24 - L)); }
+          else c1[h] = last >> (8 * (16 - L));
+        }
+      }
+    }
+    uint64_t i0[NQ], i1[NQ], i2[NQ];  // the same bytes as symbol indices
+    uint32_t flags[NQ];
+    SeedEntry ev[NQ];
+#pragma unroll
+    for (int h = 0; h < NQ; h++) {
+      uint32_t slot = 0, mul = 1, fl = 0;  // 20^7 < 2^32
+      auto word = [&](uint64_t c, int base) {
+        uint64_t iw = 0;
+#pragma unroll
+        for (int bj = 0; bj < 8; bj++) {
+          const int j = base + bj;
+          if (j < L) {
+            const uint32_t t = lut[(c >> (8 * bj)) & 0xFF];
+            fl |= t & 0x8000u;
+            iw |= (uint64_t)(t & 0x1Fu) << (8 * bj);
+            if (j >= rem) {  // seed window: leftmost residue least significant
+              fl |= t & 0x4000u;
+              slot += ((t >> 8) & 0x1Fu) * mul;
+              mul *= 20u;
+            }
+          }
+        }
+        return iw;
+      };
+      i0[h] = word(c0[h], 0);
+      i1[h] = word(c1[h], 8);
+      i2[h] = word(c2[h], 16);
+      flags[h] = fl;
+      ev[h] = SeedEntry{1u, 0u};
+      if (qv[h] < n && !fl) ev[h] = seed[slot];
+    }
+    bool listed[NQ], vfy[NQ], multi[NQ];
+    uint64_t value[NQ], t0[NQ], t1[NQ], t2[NQ];
+#pragma unroll
+    for (int h = 0; h < NQ; h++) {
+      const SeedEntry e = ev[h];
+      const uint32_t scnt = e.cnt & AA_SEED_CNT_SAT;
+      listed[h] = vfy[h] = multi[h] = false;
+      value[h] = 0;
+      t0[h] = t1[h] = t2[h] = 0;
+      if (qv[h] >= n) continue;
+      if (flags[h]) listed[h] = true;
+      else if (scnt == 0u) value[h] = 0;
+      else if (rem == 0) { if (scnt == AA_SEED_CNT_SAT) listed[h] = true; else value[h] = scnt; }
+      else if (scnt == 1u) {
+        const int jn = rem - 1;  // the residue in front of the seed window must be BWT[row]
+        const uint64_t wn = jn < 8 ? i0[h] : (jn < 16 ? i1[h] : i2[h]);
+        if ((uint32_t)((wn >> (8 * (jn & 7))) & 0xFF) != (e.cnt >> 27)) value[h] = 0;
+        else if (pos) {
+          if (e.sp >= (uint32_t)rem) {  // else the suffix starts too close to the text's beginning
+            vfy[h] = true;  // the window's loads are issued here, for all NQ queries, and compared below
+            const uint8_t* t = ix.text8 + ((uint64_t)e.sp - (uint64_t)rem);
+            t0[h] = ld8(t);
+            if (rem > 8) t1[h] = ld8(t + 8);
+            if (rem > 16) t2[h] = ld8(t + 16);
+          }
+        } else listed[h] = true;
+      } else if (pos && scnt <= (uint32_t)AA_KMER_VMULTI) multi[h] = true;
+      else listed[h] = true;
+    }
+#pragma unroll
+    for (int h = 0; h < NQ; h++) {
+      if (vfy[h]) value[h] = (((t0[h] ^ i0[h]) & m0) | ((t1[h] ^ i1[h]) & m1) | ((t2[h] ^ i2[h]) & m2)) ? 0ull : 1ull;
+      // A handful of candidate rows, neighbours in the dense SA: each is compared with the text -- two dependent loads
+      // the whole wave waits for, so a wave does it only when enough of its lanes need it (a batch of k-mers from the
+      // text); the odd such lane of a random batch is listed, and the second pass works through those densely.
+      // (Queueing them in LDS until a wave-full is pending, as the nucleotide probe does, was measured: the work
+      // moves from the second pass into this one and the sum grows by 6 %.)
+      const uint64_t mm = __ballot(multi[h]);
+      if (__popcll(mm) < AA_KMER_VMULTI_LANES) { listed[h] = listed[h] || multi[h]; multi[h] = false; }
+      if (multi[h]) {
+        const uint32_t sp = ev[h].sp, nc = ev[h].cnt & AA_SEED_CNT_SAT;
+        uint32_t p[AA_KMER_VMULTI];
+#pragma unroll
+        for (int c = 0; c < AA_KMER_VMULTI; c++) p[c] = (uint32_t)c < nc ? ix.dense_sa[sp + c] : 0u;
+        value[h] = candidates(p, nc, i0[h], i1[h], i2[h]);
+      }
+      if (qv[h] < n && !listed[h]) {
+        counts[qv[h]] = value[h];
+        if (status) status[qv[h]] = Q_OK;
+      }
+      const uint64_t lm = __ballot(listed[h]);
+      if (lm) {
+        unsigned int slot0 = 0;
+        if (lane == 0) slot0 = atomicAdd(&s_count, (unsigned int)__popcll(lm));
+        slot0 = __shfl(slot0, 0, 64);
+        if (listed[h]) ql.q[region + slot0 + (uint64_t)__popcll(lm & lane_lt)] = (uint32_t)qv[h];
+      }
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) ql.count[blockIdx.x] = s_count;
 }
 
 // one step / one backstep / one initial range for the scalar conveniences of the C ABI

@@ -863,3 +863,93 @@ def test_amino_seed_table_does_not_change_counts(oracle):
         assert np.array_equal(ix.parallel_count_csr(qb, qo), want_c), k
         got = ix.parallel_locate_csr(qb, qo)
         assert all(np.array_equal(x, y) for x, y in zip(got, want_l)), k
+
+
+@pytest.mark.parametrize("L", [7, 8, 9, 12, 15, 16, 17, 23, 24, 25])
+def test_amino_kmer_two_phase_schedule(oracle, L):
+    """equal-length amino batches (BASELINE configs[3] shape): the per-lane probe pass plus the generic kernel on what it
+    lists, device-resident (awry_dev_count_ascii_uniform) and through parallel_count, against the oracle and against the
+    generic kernel with offsets -- residues from the text, random ones, X / unknown letters / lower case anywhere, with
+    every seed length the table can have (also none) and with the accelerators on and off"""
+    import torch
+    text, st, hd = synth.make_text(300000, 1, 91, 40, 0.02)
+    # a repeated region: seed entries with several rows and queries with several occurrences
+    text = text.copy()
+    text[200000:201000] = text[1000:2000]
+    ix = gpu_index(text, 1, 8, 0, st, hd)
+    oi = oracle.OracleIndex.from_text(text, 1, 8, 0, st, hd)
+    rng = np.random.default_rng(L)
+    nq = 20000
+    pres = synth.sampled_queries(text, nq // 2, L, 5 + L, False, 1)
+    pres[: nq // 8] = synth.sampled_queries(text[1000:2000], nq // 8, L, 9, False, 1)
+    rnd = synth.random_queries(nq // 2, L, 1, 200 + L)
+    q2d = np.concatenate([pres, rnd])
+    sub = rng.random(nq) < 0.3  # one substitution somewhere
+    cols = rng.integers(0, L, size=nq)
+    q2d[sub, cols[sub]] = synth.AA[rng.integers(0, len(synth.AA), size=int(sub.sum()))]
+    odd = rng.random(nq) < 0.05  # X, letters outside the alphabet, digits: all search as X
+    q2d[odd, cols[odd]] = np.frombuffer(b"XBZJ7*", dtype=np.uint8)[rng.integers(0, 6, size=int(odd.sum()))]
+    low = rng.random(nq) < 0.1
+    q2d[low] |= 0x20
+    q2d = q2d[rng.permutation(nq)]
+    qb = np.ascontiguousarray(q2d.reshape(-1))
+    qo = (np.arange(nq + 1, dtype=np.uint64) * np.uint64(L))
+    want, _ = oi.parallel_count(qb, qo, 4)
+    assert (want > 1).sum() > 100 and (want == 1).sum() > 1000 and (want == 0).sum() > 1000
+    dev = torch.device("cuda", 0)
+    d_q = torch.from_numpy(np.concatenate([qb, np.zeros(16, dtype=np.uint8)])).to(dev)
+    d_off = torch.from_numpy(qo.astype(np.int64)).to(dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    for verify in (2, -1):
+        ix.set_verify(verify)
+        for k in (-1, 0, 1, 3, 5):
+            ix.set_seed_kmer_len(k)
+            d_c = torch.full((nq,), -1, dtype=torch.int64, device=dev)
+            d_s = torch.full((nq,), 77, dtype=torch.uint8, device=dev)
+            ix.dev_count_ascii_uniform(d_q.data_ptr(), nq, L, d_c.data_ptr(), d_s.data_ptr(), stream, 0)
+            d_c2 = torch.zeros(nq, dtype=torch.int64, device=dev)
+            ix.dev_count_ascii(d_q.data_ptr(), d_off.data_ptr(), nq, d_c2.data_ptr(), None, None, stream, 0)
+            torch.cuda.synchronize()
+            assert np.array_equal(d_c.cpu().numpy().astype(np.uint64), want), (verify, k)
+            assert np.array_equal(d_c2.cpu().numpy().astype(np.uint64), want), (verify, k)
+            assert int(d_s.max()) == 0
+            assert np.array_equal(ix.parallel_count_csr(qb, qo), want), (verify, k)
+    # undefined bytes are named by the same pass that counts the rest
+    bad = q2d.copy()
+    bad[777, L // 2] = ord("$")
+    bad[4242, L - 1] = 0xC3
+    d_qb = torch.from_numpy(np.concatenate([bad.reshape(-1), np.zeros(16, dtype=np.uint8)])).to(dev)
+    d_s = torch.zeros(nq, dtype=torch.uint8, device=dev)
+    d_c = torch.zeros(nq, dtype=torch.int64, device=dev)
+    ix.set_verify(2)
+    ix.set_seed_kmer_len(-1)
+    ix.dev_count_ascii_uniform(d_qb.data_ptr(), nq, L, d_c.data_ptr(), d_s.data_ptr(), stream, 0)
+    torch.cuda.synchronize()
+    st_h = d_s.cpu().numpy()
+    assert sorted(np.nonzero(st_h)[0].tolist()) == [777, 4242] and st_h[777] == 2 and st_h[4242] == 3
+    ok = np.ones(nq, dtype=bool)
+    ok[[777, 4242]] = False
+    assert np.array_equal(d_c.cpu().numpy().astype(np.uint64)[ok], want[ok])
+    with pytest.raises(AwryError) as e:
+        ix.parallel_count_csr(np.ascontiguousarray(bad.reshape(-1)), qo)
+    assert e.value.code == ERR_INVALID_QUERY and "query 777" in str(e.value)
+
+
+def test_uniform_entry_point_on_a_nucleotide_index(oracle):
+    """awry_dev_count_ascii_uniform without the amino schedule: the generic kernel addressing query q at q * len"""
+    import torch
+    text, st, hd = synth.make_text(200000, 0, 5, 2, 0.03)
+    ix = gpu_index(text, 0, 8, 0, st, hd)
+    oi = oracle.OracleIndex.from_text(text, 0, 8, 0, st, hd)
+    dev = torch.device("cuda", 0)
+    for L in (1, 5, 21, 40):
+        q2d = np.concatenate([synth.sampled_queries(text, 3000, L, L, True, 0), synth.random_queries(3000, L, 0, L + 1)])
+        q2d[::97, L // 2] = ord("N")
+        qb = np.ascontiguousarray(q2d.reshape(-1))
+        qo = np.arange(len(q2d) + 1, dtype=np.uint64) * np.uint64(L)
+        want, _ = oi.parallel_count(qb, qo, 4)
+        d_q = torch.from_numpy(np.concatenate([qb, np.zeros(16, dtype=np.uint8)])).to(dev)
+        d_c = torch.zeros(len(q2d), dtype=torch.int64, device=dev)
+        ix.dev_count_ascii_uniform(d_q.data_ptr(), len(q2d), L, d_c.data_ptr(), None, torch.cuda.current_stream().cuda_stream, 0)
+        torch.cuda.synchronize()
+        assert np.array_equal(d_c.cpu().numpy().astype(np.uint64), want), L

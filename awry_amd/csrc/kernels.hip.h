@@ -16,6 +16,8 @@
 //
 // Kernel map (default in CAPS; the others are kept as measured alternatives):
 //   count, any query      COUNT_SCALAR_KERNEL<A>             ASCII + offsets, one query per lane, seed probe, verify against text8
+//   count, amino k-mers   COUNT_AA_KMER_PROBE_KERNEL         equal-length ASCII residues, one query per lane: entry / text decide most
+//                         + COUNT_SCALAR_KERNEL<AMINO, LIST> the generic kernel on the listed rest
 //   count, packed k-mers  COUNT_NT2_PROBE_KERNEL             phase 1: one query per lane, entry / context / text decide most
 //                         + COUNT_NT2_RESUME_KERNEL          phase 2: quads resume the listed survivors (sparse seed tables)
 //                         COUNT_NT2_QUAD4_KERNEL             groups of four queries per quad (dense seed tables)

@@ -468,7 +468,10 @@ void launch_count_ascii_uniform(Replica& r, const uint8_t* d_q, uint64_t n, uint
   }
   if (!sc->count.p) sc->count.alloc(nblk);
   const QueryList ql{sc->q.p, sc->count.p, per_block};
-  // two queries in flight per lane (one: the same rate; four: 141 VGPRs, 10 % slower)
+  // Two queries in flight per lane (one: the same rate; four: 141 VGPRs, 10 % slower).  The second pass is a latency
+  // chain over a few per cent of the batch; running it for the first half of a batch on a side stream beside the first
+  // pass of the second half (event fork / join) was measured and costs more than it hides (12.7 -> 10.7 G present
+  // 12-mers/s, host path 0.83 -> 0.52 G queries/s).
   hipLaunchKernelGGL(count_aa_kmer_probe_kernel<2>, dim3(nblk), dim3(256), 0, s, r.dev, d_q, n, (int)L, d_counts, d_status, ql);
   hipLaunchKernelGGL((count_scalar_kernel<AMINO, true>), dim3(nblk), dim3(256), 0, s, r.dev, d_q, nullptr, n, d_counts, nullptr, d_status, 1, L, ql);
   HIP_CHECK(hipGetLastError());

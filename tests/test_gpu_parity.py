@@ -953,3 +953,38 @@ def test_uniform_entry_point_on_a_nucleotide_index(oracle):
         ix.dev_count_ascii_uniform(d_q.data_ptr(), len(q2d), L, d_c.data_ptr(), None, torch.cuda.current_stream().cuda_stream, 0)
         torch.cuda.synchronize()
         assert np.array_equal(d_c.cpu().numpy().astype(np.uint64), want), L
+
+
+def test_amino_kmer_schedule_on_a_large_batch(oracle):
+    """a batch of millions of amino k-mers (every block of the grid sees several rounds of queries and keeps a list of its
+    own): same counts as the oracle, call after call on the same stream (the lists are reused) and on another stream"""
+    import torch
+    text, st, hd = synth.make_text(2_000_000, 1, 93, 300, 0.01)
+    ix = gpu_index(text, 1, 8, 0, st, hd)
+    oi = oracle.OracleIndex.from_text(text, 1, 8, 0, st, hd)
+    L, nq = 12, 2_300_001
+    q2d = np.concatenate([synth.sampled_queries(text, nq // 2, L, 3, False, 1), synth.random_queries(nq - nq // 2, L, 1, 4)])
+    q2d = q2d[np.random.default_rng(1).permutation(nq)]
+    qb = np.ascontiguousarray(q2d.reshape(-1))
+    qo = np.arange(nq + 1, dtype=np.uint64) * np.uint64(L)
+    want, _ = oi.parallel_count(qb, qo, 8)
+    dev = torch.device("cuda", 0)
+    d_q = torch.from_numpy(qb).to(dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    outs = []
+    for rep in range(3):  # back to back: the lists of one call are reused by the next
+        d_c = torch.full((nq,), -1, dtype=torch.int64, device=dev)
+        d_s = torch.full((nq,), 9, dtype=torch.uint8, device=dev)
+        ix.dev_count_ascii_uniform(d_q.data_ptr(), nq, L, d_c.data_ptr(), d_s.data_ptr(), stream, 0)
+        outs.append((d_c, d_s))
+    torch.cuda.synchronize()
+    for d_c, d_s in outs:
+        assert np.array_equal(d_c.cpu().numpy().astype(np.uint64), want)
+        assert int(d_s.max()) == 0
+    side = torch.cuda.Stream()  # and on another stream of the caller's
+    with torch.cuda.stream(side):
+        d_c = torch.zeros(nq, dtype=torch.int64, device=dev)
+        ix.dev_count_ascii_uniform(d_q.data_ptr(), nq, L, d_c.data_ptr(), None, side.cuda_stream, 0)
+    side.synchronize()
+    assert np.array_equal(d_c.cpu().numpy().astype(np.uint64), want)
+    assert np.array_equal(ix.parallel_count_csr(qb, qo), want)

@@ -1,6 +1,7 @@
 """extended differential fuzz against the oracle (not part of the test suite): many seeded indexes of 1..200 K symbols,
 thousands of mixed queries each, host batch entry points and the single-query entry points, default device policies.
-usage: fuzz_gpu.py [trials] [seed]"""
+usage: fuzz_gpu.py [trials] [seed] [aa]   (aa: only equal-length amino batches of 6..26 residues, >= 5000 queries -- the
+amino k-mer schedule of the host pipeline)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -12,10 +13,11 @@ from tests import synth
 oracle_ffi.build()
 trials = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 99)
+only_aa = len(sys.argv) > 3 and sys.argv[3] == "aa"
 t0 = time.time()
 for trial in range(trials):
-    alphabet = int(rng.integers(0, 2))
-    n = int(rng.choice([5, 40, 300, 3000, 20000, 200000]))
+    alphabet = 1 if only_aa else int(rng.integers(0, 2))
+    n = int(rng.choice([300, 3000, 20000, 200000] if only_aa else [5, 40, 300, 3000, 20000, 200000]))
     recs = int(min(max(1, n // 50), rng.integers(1, 9)))
     nfrac = float(rng.choice([0.0, 0.02, 0.3])) if alphabet == 0 else 0.0
     ratio = int(rng.choice([1, 3, 8, 16]))
@@ -25,12 +27,16 @@ for trial in range(trials):
         for s in rng.integers(0, n - 100, size=40):
             if not (text[s:s + 60] == ord("N")).any() and not np.isin(np.arange(s, s + 60), np.array(st[1:]) - 1).any():
                 text[s:s + 60] = unit
+    if only_aa and rng.random() < 0.4:  # ambiguity residues in the text, and so in the queries drawn from it
+        text[rng.integers(0, n, size=max(1, n // 40))] = ord("X")
     ix = awry_amd.FmIndex.from_text(text, alphabet, ratio, 0, st, hd).set_devices([0])
     oi = oracle_ffi.OracleIndex.from_text(text, alphabet, ratio, 0, st, hd)
     letters = np.frombuffer(b"ACGT" if alphabet == 0 else b"ACDEFGHIKLMNPQRSTVWY", np.uint8)
     mode = int(rng.integers(0, 3))  # 0 fixed length, 1 ragged, 2 ragged with ambiguity letters / lower case
     nq = int(rng.choice([1, 70, 5000, 30000]))
     Lfix = int(rng.integers(1, min(120, n) + 1))
+    if only_aa:
+        mode, nq, Lfix = 0, int(rng.choice([5000, 12000])), int(rng.integers(6, 27))
     qs = []
     for i in range(nq):
         L = Lfix if mode == 0 else int(rng.integers(1, min(120, n) + 1))
@@ -42,7 +48,7 @@ for trial in range(trials):
                 q[int(rng.integers(0, L))] = letters[int(rng.integers(0, len(letters)))]
         else:
             q = letters[rng.integers(0, len(letters), size=L)]
-        if (q == ord("$")).any() or (mode != 2 and not np.isin(q, letters).all()):
+        if (q == ord("$")).any() or (mode != 2 and not only_aa and not np.isin(q, letters).all()):
             q = letters[rng.integers(0, len(letters), size=L)]
         if L > 3 and not np.isin(q, letters).any():  # a run of N / X matches every window of a long N run: the GPU is fine with
             q = letters[rng.integers(0, len(letters), size=L)]  # that (tests/nheavy_gpu.py), the oracle's walks are not

@@ -352,7 +352,7 @@ __global__ __launch_bounds__(256) void count_scalar_kernel(DevIndex ix, const ui
 // candidate through the dense SA, when enough lanes of the wave hold one.  Everything else -- a non-standard residue
 // in the seed window, bytes the reference leaves undefined, entries with more rows, row seeds -- is listed per block
 // and redone by count_scalar_kernel<AMINO, true> on the same grid.  The generic kernel spends ~1 900 wave instructions
-// per 64 such queries, most of them offset and byte-stream bookkeeping; this pass ~350.
+// per 64 such queries, most of them offset and byte-stream bookkeeping; this pass executes 300-400 (counted in the ISA for L = 12).
 constexpr int AA_KMER_MIN = 8, AA_KMER_MAX = 24;
 constexpr int AA_KMER_VMULTI = 4;        // seed ranges of up to this many rows are verified candidate by candidate
 constexpr int AA_KMER_VMULTI_LANES = 8;  //   when at least this many lanes of the wave hold one

@@ -109,8 +109,8 @@ struct PackedLane {
   DevBuf<uint32_t> lens, bad_list;      // bad_list: the chunk's queries with bytes outside ACGT
   DevBuf<uint8_t> status;               // generic kernel: per-query status of the chunk,
   PinBuf<uint8_t> h_status;             //   and where the host reads it
-  DevBuf<unsigned long long> bad;
-  unsigned long long* h_bad = nullptr;  // pinned
+  DevBuf<unsigned long long> bad;       // [0] number of listed queries, [1] first rejected query (index << 8 | status) or ~0
+  unsigned long long* h_bad = nullptr;  // pinned copy of both
   uint64_t chunk_lo = 0, chunk_hi = 0;
   bool busy = false;
   ~PackedLane() {
@@ -436,9 +436,9 @@ void launch_count_ascii(Replica& r, const uint8_t* d_q, const uint64_t* d_off, u
   const dim3 g(grid_for(r, n, 256)), b(256);
   const QueryList none{};
   if (r.dev.alphabet == NUCLEOTIDE)
-    hipLaunchKernelGGL((count_scalar_kernel<NUCLEOTIDE, false>), g, b, 0, s, r.dev, d_q, d_off, n, d_counts, d_ranges, d_status, allow_verify ? 1 : 0, ulen, none);
+    hipLaunchKernelGGL((count_scalar_kernel<NUCLEOTIDE, LIST_NONE>), g, b, 0, s, r.dev, d_q, d_off, n, d_counts, d_ranges, d_status, allow_verify ? 1 : 0, ulen, none);
   else
-    hipLaunchKernelGGL((count_scalar_kernel<AMINO, false>), g, b, 0, s, r.dev, d_q, d_off, n, d_counts, d_ranges, d_status, allow_verify ? 1 : 0, ulen, none);
+    hipLaunchKernelGGL((count_scalar_kernel<AMINO, LIST_NONE>), g, b, 0, s, r.dev, d_q, d_off, n, d_counts, d_ranges, d_status, allow_verify ? 1 : 0, ulen, none);
   HIP_CHECK(hipGetLastError());
 }
 
@@ -467,13 +467,13 @@ void launch_count_ascii_uniform(Replica& r, const uint8_t* d_q, uint64_t n, uint
     sc->cap = 0;  // the nucleotide k-mer path re-allocates its three lists together
   }
   if (!sc->count.p) sc->count.alloc(nblk);
-  const QueryList ql{sc->q.p, sc->count.p, per_block};
+  const QueryList ql{sc->q.p, sc->count.p, per_block, nullptr, nullptr};
   // Two queries in flight per lane (one: the same rate; four: 141 VGPRs, 10 % slower).  The second pass is a latency
   // chain over a few per cent of the batch; running it for the first half of a batch on a side stream beside the first
   // pass of the second half (event fork / join) was measured and costs more than it hides (12.7 -> 10.7 G present
   // 12-mers/s, host path 0.83 -> 0.52 G queries/s).
   hipLaunchKernelGGL(count_aa_kmer_probe_kernel<2>, dim3(nblk), dim3(256), 0, s, r.dev, d_q, n, (int)L, d_counts, d_status, ql);
-  hipLaunchKernelGGL((count_scalar_kernel<AMINO, true>), dim3(nblk), dim3(256), 0, s, r.dev, d_q, nullptr, n, d_counts, nullptr, d_status, 1, L, ql);
+  hipLaunchKernelGGL((count_scalar_kernel<AMINO, LIST_BLOCK>), dim3(nblk), dim3(256), 0, s, r.dev, d_q, nullptr, n, d_counts, nullptr, d_status, 1, L, ql);
   HIP_CHECK(hipGetLastError());
 }
 
@@ -933,19 +933,17 @@ void count_shard_packed(Replica& r, const uint8_t* qbytes, const uint64_t* qoff,
   HostPin pin_off(plan.ragged ? qoff + sh.lo : nullptr, (sh.hi - sh.lo + 1) * 8);
   const auto t1 = now();
   PackedLane* lanes = r.lanes;
-  std::vector<Shard> redo;                                          // chunks redone whole,
-  std::vector<std::pair<uint64_t, std::vector<uint32_t>>> redo_sub;  // (chunk start, sorted indices) redone query by query
+  uint64_t redone = 0;
   auto retire = [&](PackedLane& ln) {
     if (!ln.busy) return;
     ln.busy = false;
     HIP_CHECK(hipEventSynchronize(ln.done));
-    const uint64_t nb = *ln.h_bad, n = ln.chunk_hi - ln.chunk_lo;
-    if (nb == 0) return;
-    if (nb > n / 8) { redo.push_back(Shard{ln.chunk_lo, ln.chunk_hi}); return; }  // mostly other letters: not worth sorting out
-    std::vector<uint32_t> idx(nb);
-    HIP_CHECK(hipMemcpy(idx.data(), ln.bad_list.p, nb * 4, hipMemcpyDeviceToHost));  // the lane is idle: the list is final
-    std::sort(idx.begin(), idx.end());
-    redo_sub.emplace_back(ln.chunk_lo, std::move(idx));
+    redone += ln.h_bad[0];
+    if (ln.h_bad[1] != ~0ull) {  // the lowest query of the chunk that the reference leaves undefined
+      ChunkBuffers cb;
+      cb.h_status.assign(1, (uint8_t)(ln.h_bad[1] & 0xFF));
+      check_status(cb, ln.chunk_lo + (ln.h_bad[1] >> 8));
+    }
   };
   // every exit, normal or not, leaves the lanes idle before the host ranges are unpinned
   struct Drain {
@@ -959,14 +957,14 @@ void count_shard_packed(Replica& r, const uint8_t* qbytes, const uint64_t* qoff,
     PackedLane& ln = lanes[li];
     ln.s = r.lane_stream[li];
     if (!ln.done) HIP_CHECK(hipEventCreateWithFlags(&ln.done, hipEventDisableTiming));
-    if (!ln.h_bad) HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&ln.h_bad), 8, hipHostMallocDefault));
+    if (!ln.h_bad) HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&ln.h_bad), 16, hipHostMallocDefault));
     if (ln.ascii.n < cap_b + 16) ln.ascii.alloc(cap_b + 16);
     if (ln.words.n < cap_q * W) ln.words.alloc(cap_q * W);
     if (ln.counts.n < cap_q) ln.counts.alloc(cap_q);
     if (plan.ragged && ln.off.n < cap_q + 1) ln.off.alloc(cap_q + 1);
     if (plan.ragged && ln.lens.n < cap_q) ln.lens.alloc(cap_q);
     if (ln.bad_list.n < cap_q) ln.bad_list.alloc(cap_q);
-    if (!ln.bad.p) ln.bad.alloc(1);
+    if (ln.bad.n < 2) ln.bad.alloc(2);
   }
   const auto t2 = now();
   int which = 0;
@@ -980,27 +978,30 @@ void count_shard_packed(Replica& r, const uint8_t* qbytes, const uint64_t* qoff,
     HIP_CHECK(hipMemcpyAsync(ln.ascii.p, qbytes + qoff[lo], nbytes, hipMemcpyHostToDevice, ln.s));
     if (plan.ragged) HIP_CHECK(hipMemcpyAsync(ln.off.p, qoff + lo, (n + 1) * 8, hipMemcpyHostToDevice, ln.s));
     HIP_CHECK(hipMemsetAsync(ln.bad.p, 0, 8, ln.s));
+    HIP_CHECK(hipMemsetAsync(ln.bad.p + 1, 0xFF, 8, ln.s));
     launch_pack_nt2(r, ln.ascii.p, plan.ragged ? ln.off.p : nullptr, qoff[lo], n, nbytes, (int)L, W, ln.words.p,
                     plan.ragged ? ln.lens.p : nullptr, ln.bad.p, ln.s, ln.bad_list.p);
     if (L <= 32 && !plan.ragged) launch_count_nt2(r, ln.words.p, n, (int)L, ln.counts.p, true, ln.s, nullptr);
     else launch_count_nt2_long(r, ln.words.p, n, (int)L, ln.counts.p, nullptr, true, ln.s, plan.ragged ? ln.lens.p : nullptr);
+    {
+      // The queries the pack kernel listed (N, IUPAC codes, 'U', '$' ...) are redone by the generic kernel where they lie,
+      // from the chunk's ASCII in HBM, and overwrite their packed counts: results never depend on the path, and a batch
+      // of real reads -- a few such reads in every chunk -- pays one small launch per chunk, no trip through the host.
+      const QueryList ql{ln.bad_list.p, nullptr, 0, ln.bad.p, ln.bad.p + 1};
+      const uint8_t* bytes = plan.ragged ? reinterpret_cast<const uint8_t*>(reinterpret_cast<uintptr_t>(ln.ascii.p) - qoff[lo]) : ln.ascii.p;
+      hipLaunchKernelGGL((count_scalar_kernel<NUCLEOTIDE, LIST_GLOBAL>), dim3((unsigned)r.num_cus * 2), dim3(256), 0, ln.s, r.dev, bytes,
+                         plan.ragged ? ln.off.p : nullptr, n, ln.counts.p, nullptr, nullptr, 1, plan.ragged ? 0 : L, ql);
+      HIP_CHECK(hipGetLastError());
+    }
     if (pin_out_thread.joinable()) pin_out_thread.join();
     HIP_CHECK(hipMemcpyAsync(counts_out + lo, ln.counts.p, n * 8, hipMemcpyDeviceToHost, ln.s));
-    HIP_CHECK(hipMemcpyAsync(ln.h_bad, ln.bad.p, 8, hipMemcpyDeviceToHost, ln.s));
+    HIP_CHECK(hipMemcpyAsync(ln.h_bad, ln.bad.p, 16, hipMemcpyDeviceToHost, ln.s));
     HIP_CHECK(hipEventRecord(ln.done, ln.s));
     ln.busy = true;
   }
   for (int li = 0; li < 2; li++) retire(lanes[li]);
-  if (trace) fprintf(stderr, "[awry] packed shard %llu queries%s: pin %.2f ms, lane setup %.2f ms, pipeline %.2f ms\n",
-                     (unsigned long long)(sh.hi - sh.lo), plan.ragged ? " (ragged)" : "", ms(t0, t1), ms(t1, t2), ms(t2, now()));
-  // queries with other bytes (N, IUPAC codes, '$' ...): the generic kernel, which also raises INVALID_QUERY where due
-  for (Shard c : redo) count_shard_generic(r, qbytes, qoff, c, counts_out);
-  for (auto& rs : redo_sub) {
-    SubBatch sb(qbytes, qoff, rs.first, rs.second);
-    std::vector<uint64_t> tmp(rs.second.size());
-    count_shard_generic(r, sb.bytes.data(), sb.off.data(), Shard{0, rs.second.size()}, tmp.data(), sb.names.data());
-    for (size_t i = 0; i < tmp.size(); i++) counts_out[rs.first + rs.second[i]] = tmp[i];
-  }
+  if (trace) fprintf(stderr, "[awry] packed shard %llu queries%s: pin %.2f ms, lane setup %.2f ms, pipeline %.2f ms, %llu redone by the generic kernel\n",
+                     (unsigned long long)(sh.hi - sh.lo), plan.ragged ? " (ragged)" : "", ms(t0, t1), ms(t1, t2), ms(t2, now()), (unsigned long long)redone);
 }
 
 // Generic kernel, pipelined like the packed path: any alphabet, any letters, any lengths (amino batches, long or very

@@ -187,15 +187,21 @@ __device__ __forceinline__ bool text_equals_query(const uint8_t* __restrict__ te
 // allow_verify (with the dense SA and ix.text8 resident): once the range has shrunk to <= 4 rows, the letters still to
 // the left are compared with the text in front of each candidate instead of being stepped one by one; ranges[2q] then
 // holds an RS_SINGLE / RS_MULTI word for the locate pass, not a row interval -- callers that need rows pass 0.
-// ulen != 0: every query has ulen bytes, back to back (off is not read).  LIST: only the queries block b of an earlier
-// pass (same grid) listed for itself, ql.q[b * ql.cap ...) -- the second phase of count_aa_kmer_probe_kernel.
+// ulen != 0: every query has ulen bytes, back to back (off is not read).
+// LIST_BLOCK: only the queries block b of an earlier pass (same grid) listed for itself, ql.q[b * ql.cap ...) -- the
+// second phase of count_aa_kmer_probe_kernel.  LIST_GLOBAL: only the *ql.total queries of one device-wide list, in any
+// order -- the reads of a packed nucleotide chunk that hold letters outside ACGT, redone in place; the first query
+// (lowest index) with a non-zero status is reported through ql.first_bad as (index << 8 | status).
+enum { LIST_NONE = 0, LIST_BLOCK = 1, LIST_GLOBAL = 2 };
 struct QueryList {
-  uint32_t* q;      // query indices, block b owns slots [b * cap, (b + 1) * cap)
-  uint32_t* count;  // listed queries per block
+  uint32_t* q;                      // query indices; LIST_BLOCK: block b owns slots [b * cap, (b + 1) * cap)
+  uint32_t* count;                  // LIST_BLOCK: listed queries per block
   uint64_t cap;
+  const unsigned long long* total;  // LIST_GLOBAL: number of listed queries
+  unsigned long long* first_bad;    // LIST_GLOBAL (nullable): min over rejected queries of (index << 8 | status)
 };
 
-template <int A, bool LIST = false>
+template <int A, int LIST = LIST_NONE>
 __global__ __launch_bounds__(256) void count_scalar_kernel(DevIndex ix, const uint8_t* __restrict__ ascii,
                                                            const uint64_t* __restrict__ off, uint64_t n,
                                                            uint64_t* __restrict__ counts, uint64_t* __restrict__ ranges,
@@ -203,11 +209,11 @@ __global__ __launch_bounds__(256) void count_scalar_kernel(DevIndex ix, const ui
   __shared__ uint8_t lut[256];
   lut[threadIdx.x] = (uint8_t)(threadIdx.x >= 128 ? 0xFF : index_of_ascii(A, (uint8_t)threadIdx.x));
   __syncthreads();
-  const uint64_t stride = LIST ? blockDim.x : (uint64_t)gridDim.x * blockDim.x;
-  const uint64_t todo = LIST ? ql.count[blockIdx.x] : n;
+  const uint64_t stride = LIST == LIST_BLOCK ? blockDim.x : (uint64_t)gridDim.x * blockDim.x;
+  const uint64_t todo = LIST == LIST_BLOCK ? ql.count[blockIdx.x] : (LIST == LIST_GLOBAL ? (uint64_t)*ql.total : n);
   const uint8_t* const ascii_bytes = ascii;
-  for (uint64_t it = LIST ? threadIdx.x : (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; it < todo; it += stride) {
-    const uint64_t q = LIST ? ql.q[(uint64_t)blockIdx.x * ql.cap + it] : it;
+  for (uint64_t it = LIST == LIST_BLOCK ? threadIdx.x : (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; it < todo; it += stride) {
+    const uint64_t q = LIST == LIST_BLOCK ? ql.q[(uint64_t)blockIdx.x * ql.cap + it] : (LIST == LIST_GLOBAL ? ql.q[it] : it);
     const uint64_t b = ulen ? q * ulen : off[q], e = ulen ? b + ulen : off[q + 1];
     ByteStream ascii(ascii_bytes);  // shadows the pointer: same indexing, 8 bytes per load
     uint8_t st = e > b ? Q_OK : Q_EMPTY;
@@ -338,6 +344,7 @@ __global__ __launch_bounds__(256) void count_scalar_kernel(DevIndex ix, const ui
       if (ranges) { ranges[2 * q] = sp; ranges[2 * q + 1] = ep; }
     }
     if (status) status[q] = st;
+    if (LIST == LIST_GLOBAL && ql.first_bad && st != Q_OK) atomicMin(ql.first_bad, ((unsigned long long)q << 8) | st);
   }
 }
 
@@ -351,7 +358,7 @@ __global__ __launch_bounds__(256) void count_scalar_kernel(DevIndex ix, const ui
 // one <= 24-B window of the text, compared word-wise; an entry of 2..AA_KMER_VMULTI rows likewise, candidate by
 // candidate through the dense SA, when enough lanes of the wave hold one.  Everything else -- a non-standard residue
 // in the seed window, bytes the reference leaves undefined, entries with more rows, row seeds -- is listed per block
-// and redone by count_scalar_kernel<AMINO, true> on the same grid.  The generic kernel spends ~1 900 wave instructions
+// and redone by count_scalar_kernel<AMINO, LIST_BLOCK> on the same grid.  The generic kernel spends ~1 900 wave instructions
 // per 64 such queries, most of them offset and byte-stream bookkeeping; this pass executes 300-400 (counted in the ISA for L = 12).
 constexpr int AA_KMER_MIN = 8, AA_KMER_MAX = 24;
 constexpr int AA_KMER_VMULTI = 4;        // seed ranges of up to this many rows are verified candidate by candidate

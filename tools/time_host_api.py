@@ -32,3 +32,16 @@ qb = synth.NT[np.random.default_rng(2).integers(0, 4, size=int(qo[-1]), dtype=np
 for rep in range(2):
     t = time.perf_counter(); c = ix.parallel_count_csr(qb, qo); dt = time.perf_counter() - t
 print("ragged 20..39: %d queries in %.1f ms -> %.1f M queries/s (ragged packed path)" % (len(lens), dt * 1e3, len(lens) / dt / 1e6))
+# reads with ambiguity letters: 0.5 % of 101-bp reads from the text get one N (the per-read fallback of the packed path)
+reads = synth.sampled_queries(text, nq // 4, 101, 9)
+qb, qo = synth.fixed_to_csr(reads)
+for rep in range(3):
+    t = time.perf_counter(); c0 = ix.parallel_count_csr(qb, qo); dt0 = time.perf_counter() - t
+withn = reads.copy()
+sel = np.random.default_rng(3).random(len(withn)) < 0.005
+withn[sel, 50] = ord("N")
+qb, qo = synth.fixed_to_csr(withn)
+for rep in range(3):
+    t = time.perf_counter(); c1 = ix.parallel_count_csr(qb, qo); dt1 = time.perf_counter() - t
+print("101-bp reads from the text: %d reads in %.1f ms (%.1f M/s); with one N in 0.5 %% of them: %.1f ms (%.1f M/s), %d reads redone" %
+      (len(reads), dt0 * 1e3, len(reads) / dt0 / 1e6, dt1 * 1e3, len(reads) / dt1 / 1e6, int(sel.sum())), flush=True)

@@ -127,17 +127,11 @@ struct LocateLane {
   DevBuf<uint32_t> lens, bad_list;
   DevBuf<uint8_t> status;                      // generic kernel: per-query status of the chunk,
   PinBuf<uint8_t> h_status;                    //   and where the host reads it
-  std::vector<uint32_t> h_list;                // sorted chunk-relative indices of the queries redone by the generic kernels
-  std::vector<uint64_t> sub_counts;            //   and their hit counts
-  bool merge = false;                          // some of them have hits: stage 3 interleaves the two result sets
-  DevBuf<unsigned long long> bad;
-  PinBuf<uint64_t> h_counts, h_gpos, h_meta;  // h_meta: [0] total hits of the chunk, [1] reads with bytes outside ACGT
+  DevBuf<unsigned long long> bad;              // [0] reads with bytes outside ACGT, [1] first rejected read (index << 8 | status) or ~0
+  PinBuf<uint64_t> h_counts, h_gpos, h_meta;  // h_meta: [0] total hits of the chunk, [1..2] copy of `bad`
   PinBuf<awry_pos_t> h_pos;
   uint64_t lo = 0, hi = 0, total = 0;
   int stage = 0;                               // 0 idle, 1 count queued, 2 locate queued
-  std::vector<uint64_t> fb_gpos, fb_counts;    // a chunk redone by the generic kernel keeps its results here
-  std::vector<awry_pos_t> fb_pos;
-  bool fallback = false;
   ~LocateLane() {
     if (counted) (void)hipEventDestroy(counted);
     if (located) (void)hipEventDestroy(located);
@@ -467,7 +461,7 @@ void launch_count_ascii_uniform(Replica& r, const uint8_t* d_q, uint64_t n, uint
     sc->cap = 0;  // the nucleotide k-mer path re-allocates its three lists together
   }
   if (!sc->count.p) sc->count.alloc(nblk);
-  const QueryList ql{sc->q.p, sc->count.p, per_block, nullptr, nullptr};
+  const QueryList ql{sc->q.p, sc->count.p, per_block, nullptr, nullptr, 0};
   // Two queries in flight per lane (one: the same rate; four: 141 VGPRs, 10 % slower).  The second pass is a latency
   // chain over a few per cent of the batch; running it for the first half of a batch on a side stream beside the first
   // pass of the second half (event fork / join) was measured and costs more than it hides (12.7 -> 10.7 G present
@@ -803,12 +797,11 @@ void run_count_chunk(Replica& r, ChunkBuffers& cb, const uint8_t* qbytes, const 
   HIP_CHECK(hipMemcpyAsync(cb.h_status.data(), cb.status.p, n, hipMemcpyDeviceToHost, r.stream));
 }
 
-// names[i] (if given) is the batch index of the chunk's query i -- for sub-batches gathered out of a larger one
-void check_status(const ChunkBuffers& cb, uint64_t first_query, const uint64_t* names = nullptr) {
+void check_status(const ChunkBuffers& cb, uint64_t first_query) {
   for (size_t i = 0; i < cb.h_status.size(); i++)
     if (cb.h_status[i] != Q_OK) {
       static const char* why[] = {"", "empty query", "query contains '$' or '#'", "query contains a non-ASCII byte"};
-      throw QueryError("query " + std::to_string(names ? names[first_query + i] : first_query + i) + ": " + why[cb.h_status[i] & 3] +
+      throw QueryError("query " + std::to_string(first_query + i) + ": " + why[cb.h_status[i] & 3] +
                        " (undefined in the reference: src/fm_index.rs:406, src/bwt.rs:126-128)");
     }
 }
@@ -889,23 +882,7 @@ std::vector<Shard> packed_chunks(const uint64_t* qoff, Shard sh, uint64_t max_q,
 
 void launch_count_nt2(Replica& r, const uint64_t* d_words, uint64_t n, int L, uint64_t* d_counts, bool use_seed, hipStream_t s,
                       unsigned long long* d_tally);
-void count_shard_generic(Replica& r, const uint8_t* qbytes, const uint64_t* qoff, Shard sh, uint64_t* counts_out,
-                         const uint64_t* names = nullptr);
-
-// The queries `idx` (sorted batch indices) gathered into a batch of their own: bytes, offsets and batch indices.
-struct SubBatch {
-  std::vector<uint8_t> bytes;
-  std::vector<uint64_t> off, names;
-  SubBatch(const uint8_t* qbytes, const uint64_t* qoff, uint64_t base, const std::vector<uint32_t>& idx) {
-    off.assign(1, 0);
-    for (uint32_t i : idx) {
-      const uint64_t q = base + i;
-      bytes.insert(bytes.end(), qbytes + qoff[q], qbytes + qoff[q + 1]);
-      off.push_back(bytes.size());
-      names.push_back(q);
-    }
-  }
-};
+void count_shard_generic(Replica& r, const uint8_t* qbytes, const uint64_t* qoff, Shard sh, uint64_t* counts_out);
 
 void count_shard_packed(Replica& r, const uint8_t* qbytes, const uint64_t* qoff, Shard sh, PackedPlan plan, uint64_t* counts_out) {
   const uint64_t L = plan.Lmax;
@@ -987,7 +964,7 @@ void count_shard_packed(Replica& r, const uint8_t* qbytes, const uint64_t* qoff,
       // The queries the pack kernel listed (N, IUPAC codes, 'U', '$' ...) are redone by the generic kernel where they lie,
       // from the chunk's ASCII in HBM, and overwrite their packed counts: results never depend on the path, and a batch
       // of real reads -- a few such reads in every chunk -- pays one small launch per chunk, no trip through the host.
-      const QueryList ql{ln.bad_list.p, nullptr, 0, ln.bad.p, ln.bad.p + 1};
+      const QueryList ql{ln.bad_list.p, nullptr, 0, ln.bad.p, ln.bad.p + 1, 0};
       const uint8_t* bytes = plan.ragged ? reinterpret_cast<const uint8_t*>(reinterpret_cast<uintptr_t>(ln.ascii.p) - qoff[lo]) : ln.ascii.p;
       hipLaunchKernelGGL((count_scalar_kernel<NUCLEOTIDE, LIST_GLOBAL>), dim3((unsigned)r.num_cus * 2), dim3(256), 0, ln.s, r.dev, bytes,
                          plan.ragged ? ln.off.p : nullptr, n, ln.counts.p, nullptr, nullptr, 1, plan.ragged ? 0 : L, ql);
@@ -1105,14 +1082,14 @@ void count_shard(Replica& r, const uint8_t* qbytes, const uint64_t* qoff, Shard 
   } else count_shard_generic(r, qbytes, qoff, sh, counts_out);
 }
 
-void count_shard_generic(Replica& r, const uint8_t* qbytes, const uint64_t* qoff, Shard sh, uint64_t* counts_out, const uint64_t* names) {
+void count_shard_generic(Replica& r, const uint8_t* qbytes, const uint64_t* qoff, Shard sh, uint64_t* counts_out) {
   HIP_CHECK(hipSetDevice(r.device));
   ChunkBuffers cb;
   for (Shard c : chunk_queries(qoff, sh.lo, sh.hi)) {
     run_count_chunk(r, cb, qbytes, qoff, c, false);
     HIP_CHECK(hipMemcpyAsync(counts_out + c.lo, cb.counts.p, (c.hi - c.lo) * 8, hipMemcpyDeviceToHost, r.stream));
     HIP_CHECK(hipStreamSynchronize(r.stream));
-    check_status(cb, c.lo, names);
+    check_status(cb, c.lo);
   }
 }
 
@@ -1179,7 +1156,7 @@ struct LocateResult {  // per shard, in query order
 
 // generic kernels, synchronous: any alphabet, ragged lengths, ambiguity codes
 void locate_chunk_generic(Replica& r, const uint8_t* qbytes, const uint64_t* qoff, Shard c, uint64_t* counts_out,
-                          std::vector<uint64_t>& gpos, std::vector<awry_pos_t>& pos, const uint64_t* names = nullptr) {
+                          std::vector<uint64_t>& gpos, std::vector<awry_pos_t>& pos) {
   ChunkBuffers cb;
   const uint64_t n = c.hi - c.lo;
   run_count_chunk(r, cb, qbytes, qoff, c, true);
@@ -1189,7 +1166,7 @@ void locate_chunk_generic(Replica& r, const uint8_t* qbytes, const uint64_t* qof
   HIP_CHECK(hipMemcpyAsync(&total, hit_off.p + n, 8, hipMemcpyDeviceToHost, r.stream));
   HIP_CHECK(hipMemcpyAsync(counts_out, cb.counts.p, n * 8, hipMemcpyDeviceToHost, r.stream));
   HIP_CHECK(hipStreamSynchronize(r.stream));
-  check_status(cb, c.lo, names);
+  check_status(cb, c.lo);
   gpos.resize(total);
   pos.resize(total);
   if (total == 0) return;
@@ -1260,9 +1237,9 @@ void locate_shard_packed(Replica& r, const uint8_t* qbytes, const uint64_t* qoff
     if (ln.counts.n < cap) ln.counts.alloc(cap);
     if (ln.hit_off.n < cap + 1) ln.hit_off.alloc(cap + 1);
     if (ln.scratch.n < scan_tiles(cap) + 1) ln.scratch.alloc(scan_tiles(cap) + 1);
-    if (!ln.bad.p) ln.bad.alloc(1);
+    if (ln.bad.n < 2) ln.bad.alloc(2);
     ln.h_counts.ensure(cap);
-    ln.h_meta.ensure(2);
+    ln.h_meta.ensure(3);
     ln.stage = 0;
   }
   auto stage1 = [&](int li, uint64_t lo, uint64_t hi) {  // count
@@ -1271,28 +1248,31 @@ void locate_shard_packed(Replica& r, const uint8_t* qbytes, const uint64_t* qoff
     const uint64_t n = hi - lo;
     ln.lo = lo;
     ln.hi = hi;
-    ln.fallback = false;
-    ln.merge = false;
-    ln.h_list.clear();
     const uint64_t nbytes = qoff[hi] - qoff[lo];
     HIP_CHECK(hipMemcpyAsync(ln.ascii.p, qbytes + qoff[lo], nbytes, hipMemcpyHostToDevice, s));
     if (plan.ragged) HIP_CHECK(hipMemcpyAsync(ln.off.p, qoff + lo, (n + 1) * 8, hipMemcpyHostToDevice, s));
     HIP_CHECK(hipMemsetAsync(ln.bad.p, 0, 8, s));
+    HIP_CHECK(hipMemsetAsync(ln.bad.p + 1, 0xFF, 8, s));
+    const uint8_t* biased = reinterpret_cast<const uint8_t*>(reinterpret_cast<uintptr_t>(ln.ascii.p) - qoff[lo]);
     if (generic) {
-      const uint8_t* biased = reinterpret_cast<const uint8_t*>(reinterpret_cast<uintptr_t>(ln.ascii.p) - qoff[lo]);
       launch_count_ascii(r, biased, ln.off.p, n, ln.counts.p, ln.rstart.p, ln.status.p, s, true);
       HIP_CHECK(hipMemcpyAsync(ln.h_status.p, ln.status.p, n, hipMemcpyDeviceToHost, s));
     } else {
       launch_pack_nt2(r, ln.ascii.p, plan.ragged ? ln.off.p : nullptr, qoff[lo], n, nbytes, (int)L, (int)W, ln.words.p,
                       plan.ragged ? ln.lens.p : nullptr, ln.bad.p, s, ln.bad_list.p);
       launch_count_nt2_long(r, ln.words.p, n, (int)L, ln.counts.p, ln.rstart.p, true, s, plan.ragged ? ln.lens.p : nullptr);
-      // reads with other bytes count as "no hits" in this pass; stage 2 redoes them with the generic kernels
-      hipLaunchKernelGGL(zero_listed_counts_kernel, dim3(64), dim3(256), 0, s, ln.bad_list.p, ln.bad.p, ln.counts.p);
+      // reads with other bytes (N, IUPAC codes ...) are redone where they lie by the generic kernel working through the
+      // pack kernel's list: it overwrites their counts and range words (starts only, the packed kernels' layout) before
+      // the scan, so the locate pass and the result arrays never know the difference
+      const QueryList ql{ln.bad_list.p, nullptr, 0, ln.bad.p, ln.bad.p + 1, 1};
+      hipLaunchKernelGGL((count_scalar_kernel<NUCLEOTIDE, LIST_GLOBAL>), dim3((unsigned)r.num_cus * 2), dim3(256), 0, s, r.dev,
+                         plan.ragged ? biased : ln.ascii.p, plan.ragged ? ln.off.p : nullptr, n, ln.counts.p, ln.rstart.p, nullptr, 1,
+                         plan.ragged ? 0 : L, ql);
       HIP_CHECK(hipGetLastError());
     }
     launch_scan(r, ln.counts.p, n, ln.hit_off.p, ln.scratch.p, s);
     HIP_CHECK(hipMemcpyAsync(ln.h_meta.p, ln.hit_off.p + n, 8, hipMemcpyDeviceToHost, s));
-    HIP_CHECK(hipMemcpyAsync(ln.h_meta.p + 1, ln.bad.p, 8, hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipMemcpyAsync(ln.h_meta.p + 1, ln.bad.p, 16, hipMemcpyDeviceToHost, s));
     HIP_CHECK(hipMemcpyAsync(ln.h_counts.p, ln.counts.p, n * 8, hipMemcpyDeviceToHost, s));
     HIP_CHECK(hipEventRecord(ln.counted, s));
     ln.stage = 1;
@@ -1312,29 +1292,15 @@ void locate_shard_packed(Replica& r, const uint8_t* qbytes, const uint64_t* qoff
         check_status(cb, ln.lo);  // raises INVALID_QUERY naming the first such query
       }
     }
-    const uint64_t nb = generic ? 0 : ln.h_meta.p[1];
-    if (nb && nb <= n / 8) {  // a few reads with other bytes (N, IUPAC codes ...): the generic kernels redo just those
-      ln.h_list.resize(nb);
-      HIP_CHECK(hipMemcpy(ln.h_list.data(), ln.bad_list.p, nb * 4, hipMemcpyDeviceToHost));  // final: the lane's stream is idle
-      std::sort(ln.h_list.begin(), ln.h_list.end());
-      SubBatch sb(qbytes, qoff, ln.lo, ln.h_list);
-      ln.sub_counts.resize(nb);
-      locate_chunk_generic(r, sb.bytes.data(), sb.off.data(), Shard{0, nb}, ln.sub_counts.data(), ln.fb_gpos, ln.fb_pos, sb.names.data());
-      for (uint64_t i = 0; i < nb; i++) ln.h_counts.p[ln.h_list[i]] = ln.sub_counts[i];  // they were zero in the packed pass
-      ln.merge = !ln.fb_pos.empty();
-    } else if (nb) {  // mostly other bytes: the generic kernels redo the chunk (and raise INVALID_QUERY where due)
-      ln.fb_counts.resize(n);
-      locate_chunk_generic(r, qbytes, qoff, Shard{ln.lo, ln.hi}, ln.fb_counts.data(), ln.fb_gpos, ln.fb_pos);
-      out.add_counts(ln.fb_counts.data(), n);
-      ln.fallback = true;
-      ln.total = ln.fb_pos.size();
-      ln.stage = 2;
-      return;
+    if (!generic && ln.h_meta.p[2] != ~0ull) {  // the lowest read of the chunk that the reference leaves undefined
+      ChunkBuffers cb;
+      cb.h_status.assign(1, (uint8_t)(ln.h_meta.p[2] & 0xFF));
+      check_status(cb, ln.lo + (ln.h_meta.p[2] >> 8));
     }
     out.add_counts(ln.h_counts.p, n);  // stage 2 runs in chunk order
     ln.total = ln.h_meta.p[0];
     const uint64_t STAGE_CAP = 16ull << 20;  // hits the pinned staging of a lane holds at most (384 MB)
-    if (ln.total > STAGE_CAP && !ln.merge) {
+    if (ln.total > STAGE_CAP) {
       // a hit-heavy chunk (repeats, N runs): the positions come back in pieces through the bounded staging, appended
       // here -- every earlier chunk has been appended already (stage 3 of chunk i - 2 runs before stage 1 of chunk i)
       if (ln.gpos.n < ln.total) ln.gpos.alloc(ln.total + ln.total / 4);
@@ -1367,30 +1333,8 @@ void locate_shard_packed(Replica& r, const uint8_t* qbytes, const uint64_t* qoff
   auto stage3 = [&](int li) {  // results into the output arrays, in chunk order
     LocateLane& ln = lanes[li];
     if (ln.stage != 2) return;
-    if (ln.fallback) {
-      out.append(ln.fb_gpos.data(), ln.fb_pos.data(), ln.fb_pos.size(), want_gpos);
-    } else {
-      HIP_CHECK(hipEventSynchronize(ln.located));
-      if (!ln.merge) {
-        out.append(ln.h_gpos.p, ln.h_pos.p, ln.total, want_gpos);
-      } else {  // rare: interleave the packed pass's hits with those of the reads the generic kernels redid, in query order
-        const uint64_t n = ln.hi - ln.lo;
-        std::vector<awry_pos_t> mp(ln.total + ln.fb_pos.size());
-        std::vector<uint64_t> mg(want_gpos ? mp.size() : 0);
-        size_t pk = 0, fb = 0, w = 0, bi = 0;
-        for (uint64_t q = 0; q < n; q++) {
-          const uint64_t c = ln.h_counts.p[q];
-          const bool redone = bi < ln.h_list.size() && ln.h_list[bi] == q;
-          if (redone) bi++;
-          if (!c) continue;
-          memcpy(mp.data() + w, redone ? ln.fb_pos.data() + fb : ln.h_pos.p + pk, c * sizeof(awry_pos_t));
-          if (want_gpos) memcpy(mg.data() + w, redone ? ln.fb_gpos.data() + fb : ln.h_gpos.p + pk, c * 8);
-          (redone ? fb : pk) += c;
-          w += c;
-        }
-        out.append(mg.data(), mp.data(), w, want_gpos);
-      }
-    }
+    HIP_CHECK(hipEventSynchronize(ln.located));
+    out.append(ln.h_gpos.p, ln.h_pos.p, ln.total, want_gpos);
     ln.stage = 0;
   };
   uint64_t i = 0;

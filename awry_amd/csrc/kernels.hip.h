@@ -31,7 +31,7 @@
 //                         locate_walk_kernel<A>              generic walk (amino), locate_scalar_kernel<A> (round-1 baseline)
 //   accelerators          seed_level1/extend/finalize (+aa_*), seed_rows_to_positions_kernel, densify_sa_kernel,
 //                         nblock_sa_kernel, text4_scatter_kernel, text8_scatter_kernel
-//   glue                  pack_nt2_tile_kernel<R>, zero_listed_counts_kernel, scan_*_kernel, ref_kmer_table_kernel,
+//   glue                  pack_nt2_tile_kernel<R>, scan_*_kernel, ref_kmer_table_kernel,
 //                         scalar_ops_kernel
 #pragma once
 #include <hip/hip_runtime.h>
@@ -199,6 +199,8 @@ struct QueryList {
   uint64_t cap;
   const unsigned long long* total;  // LIST_GLOBAL: number of listed queries
   unsigned long long* first_bad;    // LIST_GLOBAL (nullable): min over rejected queries of (index << 8 | status)
+  uint32_t range_stride;            // LIST_GLOBAL: 1 = ranges[q] receives the range start / RS_* word only (the layout of
+                                    //   the packed read kernels' range_start), otherwise (start, end) pairs
 };
 
 template <int A, int LIST = LIST_NONE>
@@ -336,12 +338,13 @@ __global__ __launch_bounds__(256) void count_scalar_kernel(DevIndex ix, const ui
         step_scalar<A>(ix, sp, ep, lut[ascii[i]]);
       }
     }
+    const bool starts_only = LIST == LIST_GLOBAL && ql.range_stride == 1;
     if (verified) {
       counts[q] = vcount;
-      if (ranges) { ranges[2 * q] = vrs; ranges[2 * q + 1] = 0; }
+      if (ranges) { if (starts_only) ranges[q] = vrs; else { ranges[2 * q] = vrs; ranges[2 * q + 1] = 0; } }
     } else {
       counts[q] = sp > ep ? 0 : ep - sp + 1;  // src/search.rs:66-71
-      if (ranges) { ranges[2 * q] = sp; ranges[2 * q + 1] = ep; }
+      if (ranges) { if (starts_only) ranges[q] = sp; else { ranges[2 * q] = sp; ranges[2 * q + 1] = ep; } }
     }
     if (status) status[q] = st;
     if (LIST == LIST_GLOBAL && ql.first_bad && st != Q_OK) atomicMin(ql.first_bad, ((unsigned long long)q << 8) | st);
@@ -1552,14 +1555,6 @@ __global__ __launch_bounds__(256) void pack_nt2_tile_kernel(const uint8_t* __res
       done += m ? m : 1;
     }
   }
-}
-
-// counts[list[i]] = 0 for the *count queries the pack kernel listed (their packed words are meaningless; locate must
-// not expand hits for them before the generic kernel has redone them)
-__global__ __launch_bounds__(256) void zero_listed_counts_kernel(const uint32_t* __restrict__ list, const unsigned long long* __restrict__ count,
-                                                                 uint64_t* __restrict__ counts) {
-  const uint64_t m = *count, stride = (uint64_t)gridDim.x * blockDim.x;
-  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += stride) counts[list[i]] = 0;
 }
 
 // Packed reads of any length (W = ceil(L/32) words per query, letter j in word j/32, bits 2(j%32)): the quad design

@@ -19,3 +19,12 @@ for L in (101, 31):
         for rep in range(3):
             t = time.perf_counter(); off, g, p = ix.parallel_locate_csr(qb, qo); dt = time.perf_counter() - t
         print("L=%d %s: %d reads, %d hits in %.1f ms -> %.1f M reads/s end-to-end (PCIe-inclusive)" % (L, name, nq, len(g), dt * 1e3, nq / dt / 1e6), flush=True)
+# reads with ambiguity letters: one N in 0.5 % of the 101-bp reads (redone on the device by the generic kernel)
+ix.set_verify(2)
+q2d = synth.sampled_queries(text, nq, 101, 5)
+sel = np.random.default_rng(3).random(nq) < 0.005
+q2d[sel, 50] = ord("N")
+qb, qo = synth.fixed_to_csr(q2d)
+for rep in range(3):
+    t = time.perf_counter(); off, g, p = ix.parallel_locate_csr(qb, qo); dt = time.perf_counter() - t
+print("L=101 with one N in 0.5 %% of the reads (%d): %d hits in %.1f ms -> %.1f M reads/s" % (int(sel.sum()), len(g), dt * 1e3, nq / dt / 1e6), flush=True)

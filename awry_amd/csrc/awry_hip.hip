@@ -986,12 +986,15 @@ void count_shard_packed(Replica& r, const uint8_t* qbytes, const uint64_t* qoff,
 // reads the chunk's queries through the batch's own offsets (the ASCII pointer is biased by the chunk's first byte).
 // ulen != 0: every query of the shard has ulen bytes -- the offsets stay on the host and the kernels address query q at q * ulen.
 void count_shard_generic_pipelined(Replica& r, const uint8_t* qbytes, const uint64_t* qoff, Shard sh, uint64_t* counts_out, uint64_t ulen = 0) {
-  for (uint64_t i = sh.lo; i < sh.hi; i++)  // (vectorises) non-decreasing offsets
-    if (qoff[i + 1] < qoff[i]) throw ArgError("query offsets must be non-decreasing");
+  if (!ulen)  // (one length: the length scan has seen every offset already)
+    for (uint64_t i = sh.lo; i < sh.hi; i++)  // (vectorises) non-decreasing offsets
+      if (qoff[i + 1] < qoff[i]) throw ArgError("query offsets must be non-decreasing");
   const std::vector<Shard> chunks = packed_chunks(qoff, sh, 4u << 20, 256ull << 20);
   uint64_t cap_q = 0, cap_b = 0;
   for (Shard c : chunks) { cap_q = std::max(cap_q, c.hi - c.lo); cap_b = std::max(cap_b, qoff[c.hi] - qoff[c.lo]); }
   std::lock_guard<std::mutex> lane_lock(r.lane_mu);
+  static const bool trace = getenv("AWRY_TRACE_HOST") != nullptr;
+  const auto t0 = std::chrono::steady_clock::now();
   std::unique_ptr<HostPin> pin_out;
   std::thread pin_out_thread([&] {
     (void)hipSetDevice(r.device);
@@ -1002,6 +1005,7 @@ void count_shard_generic_pipelined(Replica& r, const uint8_t* qbytes, const uint
     ~Joiner() { if (t.joinable()) t.join(); }
   } joiner{pin_out_thread};
   HostPin pin_in(qbytes + qoff[sh.lo], qoff[sh.hi] - qoff[sh.lo]), pin_off(ulen ? nullptr : qoff + sh.lo, (sh.hi - sh.lo + 1) * 8);
+  const auto t1 = std::chrono::steady_clock::now();
   PackedLane* lanes = r.lanes;
   auto retire = [&](PackedLane& ln) {
     if (!ln.busy) return;
@@ -1057,6 +1061,11 @@ void count_shard_generic_pipelined(Replica& r, const uint8_t* qbytes, const uint
     ln.busy = true;
   }
   for (int li = 0; li < 2; li++) retire(lanes[li]);
+  if (trace) {
+    auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    fprintf(stderr, "[awry] generic shard %llu queries%s: pin %.2f ms, pipeline %.2f ms\n", (unsigned long long)(sh.hi - sh.lo),
+            ulen ? " (one length)" : "", ms(t0, t1), ms(t1, std::chrono::steady_clock::now()));
+  }
 }
 
 void count_shard(Replica& r, const uint8_t* qbytes, const uint64_t* qoff, Shard sh, uint64_t* counts_out) {
@@ -1077,6 +1086,8 @@ void count_shard(Replica& r, const uint8_t* qbytes, const uint64_t* qoff, Shard 
     if (r.dev.alphabet == AMINO) {
       const PackedPlan ap = plan_packed(qoff, sh);
       if (ap.ok && !ap.ragged) ulen = ap.Lmax;
+      if (getenv("AWRY_TRACE_HOST"))
+        fprintf(stderr, "[awry] amino length scan %.2f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
     }
     count_shard_generic_pipelined(r, qbytes, qoff, sh, counts_out, ulen);
   } else count_shard_generic(r, qbytes, qoff, sh, counts_out);

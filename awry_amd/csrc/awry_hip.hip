@@ -4,6 +4,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <sys/mman.h>
+
 #include <algorithm>
 #include <atomic>
 #include <chrono>
@@ -1106,7 +1108,8 @@ void count_shard_generic(Replica& r, const uint8_t* qbytes, const uint64_t* qoff
 
 // memcpy for result-sized buffers: fresh destination pages fault on first touch, so large copies are cut over a few threads
 void par_memcpy(void* dst, const void* src, size_t bytes) {
-  const unsigned T = bytes >= (32u << 20) ? std::min(8u, std::max(1u, std::thread::hardware_concurrency())) : 1;
+  // (from 4 MB on: a locate chunk's 8..16 MB slices used to go single-threaded and cost 16 of the 22 ms of a 4 M-read call)
+  const unsigned T = bytes >= (4u << 20) ? std::min(8u, std::max(1u, std::thread::hardware_concurrency())) : 1;
   if (T == 1) { memcpy(dst, src, bytes); return; }
   std::vector<std::thread> th;
   const size_t per = ((bytes + T - 1) / T + 4095) & ~(size_t)4095;
@@ -1121,20 +1124,33 @@ template <class T>
 struct MBuf {  // malloc'ed, geometrically growing array whose storage can be handed to the caller (awry_free_buffer = free)
   T* p = nullptr;
   size_t cap = 0;
+  size_t used_bytes = 0;  // bytes of p[] that hold data (what a re-allocation has to carry over)
   MBuf() = default;
   MBuf(const MBuf&) = delete;
   MBuf& operator=(const MBuf&) = delete;
-  MBuf(MBuf&& o) noexcept : p(o.p), cap(o.cap) { o.p = nullptr; o.cap = 0; }
+  MBuf(MBuf&& o) noexcept : p(o.p), cap(o.cap), used_bytes(o.used_bytes) { o.p = nullptr; o.cap = 0; o.used_bytes = 0; }
   ~MBuf() { free(p); }
   void grow(size_t need) {
     if (need <= cap) return;
-    const size_t c = std::max(need, cap + cap / 2 + 4096);
-    T* q = static_cast<T*>(realloc(p, c * sizeof(T)));
+    const size_t c = std::max(need, cap + cap / 2 + 4096), bytes = c * sizeof(T);
+    if (bytes >= (8u << 20)) {
+      // result-sized: 2 MB-aligned and advised for huge pages -- filling a fresh array is bound by its first-touch page
+      // faults, and a huge page takes one fault for 512 small ones (no effect where the kernel has them switched off)
+      void* q = nullptr;
+      if (posix_memalign(&q, 2u << 20, bytes) != 0 || !q) throw std::bad_alloc();
+      (void)madvise(q, bytes, MADV_HUGEPAGE);
+      if (p && used_bytes) memcpy(q, p, used_bytes);
+      free(p);
+      p = static_cast<T*>(q);
+      cap = c;
+      return;
+    }
+    T* q = static_cast<T*>(realloc(p, bytes));
     if (!q) throw std::bad_alloc();
     p = q;
     cap = c;
   }
-  T* release() { T* q = p; p = nullptr; cap = 0; return q; }
+  T* release() { T* q = p; p = nullptr; cap = 0; used_bytes = 0; return q; }
 };
 
 struct LocateResult {  // per shard, in query order
@@ -1157,9 +1173,11 @@ struct LocateResult {  // per shard, in query order
     }
     pos.grow(total + n);
     par_memcpy(pos.p + total, p, n * sizeof(awry_pos_t));
+    pos.used_bytes = (total + n) * sizeof(awry_pos_t);
     if (want_gpos) {
       gpos.grow(total + n);
       par_memcpy(gpos.p + total, g, n * 8);
+      gpos.used_bytes = (total + n) * 8;
     }
     total += n;
   }
@@ -1224,6 +1242,13 @@ void locate_shard_packed(Replica& r, const uint8_t* qbytes, const uint64_t* qoff
   HostPin pin_in(qbytes + qoff[sh.lo], qoff[sh.hi] - qoff[sh.lo]);
   HostPin pin_off(plan.ragged ? qoff + sh.lo : nullptr, (sh.hi - sh.lo + 1) * 8);
   LocateLane* lanes = r.loc_lanes;
+  double t_pin = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), t_wait_count = 0, t_wait_locate = 0, t_append = 0;
+  auto timed = [&](double& acc, auto&& fn) {
+    if (!trace) { fn(); return; }
+    const auto a = std::chrono::steady_clock::now();
+    fn();
+    acc += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a).count();
+  };
   struct Drain {  // every exit leaves the lanes idle before the input is unpinned
     Replica& r;
     ~Drain() {
@@ -1293,7 +1318,7 @@ void locate_shard_packed(Replica& r, const uint8_t* qbytes, const uint64_t* qoff
     if (ln.stage != 1) return;
     hipStream_t s = r.lane_stream[li];
     const uint64_t n = ln.hi - ln.lo;
-    HIP_CHECK(hipEventSynchronize(ln.counted));
+    timed(t_wait_count, [&] { HIP_CHECK(hipEventSynchronize(ln.counted)); });
     if (generic) {
       uint64_t any = 0;
       for (uint64_t i = 0; i < n; i++) any |= ln.h_status.p[i];
@@ -1344,8 +1369,8 @@ void locate_shard_packed(Replica& r, const uint8_t* qbytes, const uint64_t* qoff
   auto stage3 = [&](int li) {  // results into the output arrays, in chunk order
     LocateLane& ln = lanes[li];
     if (ln.stage != 2) return;
-    HIP_CHECK(hipEventSynchronize(ln.located));
-    out.append(ln.h_gpos.p, ln.h_pos.p, ln.total, want_gpos);
+    timed(t_wait_locate, [&] { HIP_CHECK(hipEventSynchronize(ln.located)); });
+    timed(t_append, [&] { out.append(ln.h_gpos.p, ln.h_pos.p, ln.total, want_gpos); });
     ln.stage = 0;
   };
   uint64_t i = 0;
@@ -1361,8 +1386,9 @@ void locate_shard_packed(Replica& r, const uint8_t* qbytes, const uint64_t* qoff
   stage2(last);
   stage3(last);
   if (trace)
-    fprintf(stderr, "[awry] packed locate shard: %llu reads, %zu hits, %.2f ms\n", (unsigned long long)(sh.hi - sh.lo), out.total,
-            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+    fprintf(stderr, "[awry] packed locate shard: %llu reads, %zu hits, %.2f ms (pin %.2f, waiting for counts %.2f, for positions %.2f, copying out %.2f)\n",
+            (unsigned long long)(sh.hi - sh.lo), out.total, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(),
+            t_pin, t_wait_count, t_wait_locate, t_append);
 }
 
 void locate_shard(Replica& r, const uint8_t* qbytes, const uint64_t* qoff, Shard sh, bool want_gpos, LocateResult& out) {
@@ -1393,11 +1419,17 @@ void for_each_replica(awry_index* ix, uint64_t n, F&& fn) {
   for (auto& e : errs) if (e) std::rethrow_exception(e);
 }
 
+// result arrays handed to the caller (released with free()); large ones 2 MB-aligned and advised for huge pages, see MBuf
 template <class T>
 T* malloc_array(size_t n) {
-  T* p = static_cast<T*>(malloc(std::max<size_t>(1, n) * sizeof(T)));
+  const size_t bytes = std::max<size_t>(1, n) * sizeof(T);
+  void* p = nullptr;
+  if (bytes >= (8u << 20)) {
+    if (posix_memalign(&p, 2u << 20, bytes) != 0) p = nullptr;
+    if (p) (void)madvise(p, bytes, MADV_HUGEPAGE);
+  } else p = malloc(bytes);
   if (!p) throw std::bad_alloc();
-  return p;
+  return static_cast<T*>(p);
 }
 
 void fill_ref_kmer_table(awry_index* ix) {
@@ -1656,6 +1688,7 @@ int awry_locate_batch(awry_index_t* idx, const uint8_t* qbytes, const uint64_t* 
   return guarded([&] {
     require(idx && qoff && hit_off_out && hits_out, "null argument");
     require(qbytes || qoff[n] == qoff[0], "null query bytes");
+    const auto t0 = std::chrono::steady_clock::now();
     std::vector<LocateResult> res(std::max<size_t>(1, idx->reps.size()));
     std::unique_ptr<uint64_t, decltype(&free)> off(malloc_array<uint64_t>(n + 1), &free);
     off.get()[0] = 0;
@@ -1686,6 +1719,8 @@ int awry_locate_batch(awry_index_t* idx, const uint8_t* qbytes, const uint64_t* 
       if (global_pos_out) *global_pos_out = gp.release();
     }
     *hit_off_out = off.release();
+    if (getenv("AWRY_TRACE_HOST"))
+      fprintf(stderr, "[awry] awry_locate_batch %.2f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
   });
 }
 

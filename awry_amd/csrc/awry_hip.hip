@@ -1711,8 +1711,8 @@ int awry_locate_batch(awry_index_t* idx, const uint8_t* qbytes, const uint64_t* 
       std::unique_ptr<uint64_t, decltype(&free)> gp(global_pos_out ? malloc_array<uint64_t>(total) : nullptr, &free);
       uint64_t at = 0;
       for (auto& x : res) {
-        if (x.total) memcpy(hits.get() + at, x.pos.p, x.total * sizeof(awry_pos_t));
-        if (gp && x.total) memcpy(gp.get() + at, x.gpos.p, x.total * 8);
+        if (x.total) par_memcpy(hits.get() + at, x.pos.p, x.total * sizeof(awry_pos_t));
+        if (gp && x.total) par_memcpy(gp.get() + at, x.gpos.p, x.total * 8);
         at += x.total;
       }
       *hits_out = hits.release();

@@ -174,7 +174,16 @@ struct Replica {
   bool verify_kmers = false;                  // also use seed-and-verify in the k-mer (L <= 32) kernel
   std::atomic<unsigned> launch_seq{0};
   // survivor lists of the two-phase count schedule, one per stream (launches on one stream are ordered, so reuse is safe)
-  struct SurvScratch { DevBuf<uint64_t> w, range; DevBuf<uint32_t> q, count; uint64_t cap = 0, cap_q = 0; };
+  struct SurvScratch {
+    DevBuf<uint64_t> w, range;
+    DevBuf<uint32_t> q, count;
+    uint64_t cap = 0, cap_q = 0;
+    // awry_dev_count_ascii_uniform on a nucleotide index: packed words of the batch, the pack kernel's list of queries with
+    // other letters and its counter
+    DevBuf<uint64_t> u_words;
+    DevBuf<uint32_t> u_list;
+    DevBuf<unsigned long long> u_bad;
+  };
   std::mutex scratch_mu;
   std::map<hipStream_t, std::unique_ptr<SurvScratch>> scratch;
   int seed_k = 0;
@@ -435,41 +444,6 @@ void launch_count_ascii(Replica& r, const uint8_t* d_q, const uint64_t* d_off, u
     hipLaunchKernelGGL((count_scalar_kernel<NUCLEOTIDE, LIST_NONE>), g, b, 0, s, r.dev, d_q, d_off, n, d_counts, d_ranges, d_status, allow_verify ? 1 : 0, ulen, none);
   else
     hipLaunchKernelGGL((count_scalar_kernel<AMINO, LIST_NONE>), g, b, 0, s, r.dev, d_q, d_off, n, d_counts, d_ranges, d_status, allow_verify ? 1 : 0, ulen, none);
-  HIP_CHECK(hipGetLastError());
-}
-
-Replica::SurvScratch* surv_scratch(Replica& r, hipStream_t s);
-
-// n ASCII queries of L bytes each, back to back: counts (and status) only.  Amino k-mers with a seed table take the
-// two-phase schedule (count_aa_kmer_probe_kernel, then the generic kernel on what it listed); anything else is the
-// generic kernel reading its queries at q * L.
-void launch_count_ascii_uniform(Replica& r, const uint8_t* d_q, uint64_t n, uint64_t L, uint64_t* d_counts, uint8_t* d_status, hipStream_t s) {
-  if (n == 0) return;
-  require(L >= 1, "query length must be at least 1");
-  static const bool off = getenv("AWRY_AA_KMER") && !strcmp(getenv("AWRY_AA_KMER"), "0");
-  const bool two_phase = !off && r.dev.alphabet == AMINO && L >= (uint64_t)AA_KMER_MIN && L <= (uint64_t)AA_KMER_MAX && r.seed_k >= 1 &&
-                         (uint64_t)r.seed_k <= L && n < (1ull << 32);
-  if (!two_phase) {
-    launch_count_ascii(r, d_q, nullptr, n, d_counts, nullptr, d_status, s, true, L);
-    return;
-  }
-  Replica::SurvScratch* sc = surv_scratch(r, s);
-  const unsigned nblk = (unsigned)r.num_cus * 8;  // both phases use this grid
-  const uint64_t per_block = ((n + (uint64_t)nblk * 256 - 1) / ((uint64_t)nblk * 256)) * 256;  // queries a block sees
-  if (sc->cap_q < per_block * nblk) {
-    HIP_CHECK(hipStreamSynchronize(s));
-    sc->q.alloc(per_block * nblk);
-    sc->cap_q = per_block * nblk;
-    sc->cap = 0;  // the nucleotide k-mer path re-allocates its three lists together
-  }
-  if (!sc->count.p) sc->count.alloc(nblk);
-  const QueryList ql{sc->q.p, sc->count.p, per_block, nullptr, nullptr, 0};
-  // Two queries in flight per lane (one: the same rate; four: 141 VGPRs, 10 % slower).  The second pass is a latency
-  // chain over a few per cent of the batch; running it for the first half of a batch on a side stream beside the first
-  // pass of the second half (event fork / join) was measured and costs more than it hides (12.7 -> 10.7 G present
-  // 12-mers/s, host path 0.83 -> 0.52 G queries/s).
-  hipLaunchKernelGGL(count_aa_kmer_probe_kernel<2>, dim3(nblk), dim3(256), 0, s, r.dev, d_q, n, (int)L, d_counts, d_status, ql);
-  hipLaunchKernelGGL((count_scalar_kernel<AMINO, LIST_BLOCK>), dim3(nblk), dim3(256), 0, s, r.dev, d_q, nullptr, n, d_counts, nullptr, d_status, 1, L, ql);
   HIP_CHECK(hipGetLastError());
 }
 
@@ -806,6 +780,60 @@ void check_status(const ChunkBuffers& cb, uint64_t first_query) {
       throw QueryError("query " + std::to_string(first_query + i) + ": " + why[cb.h_status[i] & 3] +
                        " (undefined in the reference: src/fm_index.rs:406, src/bwt.rs:126-128)");
     }
+}
+
+// n ASCII queries of L bytes each, back to back: counts (and status) only.  Nucleotide: packed on the device and served by
+// the packed kernels.  Amino k-mers with a seed table: the two-phase schedule (count_aa_kmer_probe_kernel, then the
+// generic kernel on what it listed).  Anything else: the generic kernel reading its queries at q * L.
+void launch_count_ascii_uniform(Replica& r, const uint8_t* d_q, uint64_t n, uint64_t L, uint64_t* d_counts, uint8_t* d_status, hipStream_t s) {
+  if (n == 0) return;
+  require(L >= 1, "query length must be at least 1");
+  static const bool off = getenv("AWRY_AA_KMER") && !strcmp(getenv("AWRY_AA_KMER"), "0");
+  const bool two_phase = !off && r.dev.alphabet == AMINO && L >= (uint64_t)AA_KMER_MIN && L <= (uint64_t)AA_KMER_MAX && r.seed_k >= 1 &&
+                         (uint64_t)r.seed_k <= L && n < (1ull << 32);
+  Replica::SurvScratch* sc = surv_scratch(r, s);
+  if (r.dev.alphabet == NUCLEOTIDE && r.dev.bwt_len < (1ull << 32) - 512 && L <= 4096 && n < (1ull << 32)) {
+    // the device half of the packed host path: pack 2 bits per letter, packed kernels, and the generic kernel over the
+    // pack kernel's list for the queries with letters outside ACGT (it also writes their status)
+    const uint64_t W = (L + 31) / 32;
+    if (sc->u_words.n < n * W || sc->u_list.n < n || !sc->u_bad.p) {
+      HIP_CHECK(hipStreamSynchronize(s));
+      if (sc->u_words.n < n * W) sc->u_words.alloc(n * W + n * W / 4);
+      if (sc->u_list.n < n) sc->u_list.alloc(n + n / 4);
+      if (!sc->u_bad.p) sc->u_bad.alloc(2);
+    }
+    HIP_CHECK(hipMemsetAsync(sc->u_bad.p, 0, 16, s));
+    if (d_status) HIP_CHECK(hipMemsetAsync(d_status, 0, n, s));
+    launch_pack_nt2(r, d_q, nullptr, 0, n, n * L, (int)L, (int)W, sc->u_words.p, nullptr, sc->u_bad.p, s, sc->u_list.p);
+    if (L <= 32) launch_count_nt2(r, sc->u_words.p, n, (int)L, d_counts, true, s, nullptr);
+    else launch_count_nt2_long(r, sc->u_words.p, n, (int)L, d_counts, nullptr, true, s, nullptr);
+    const QueryList ql{sc->u_list.p, nullptr, 0, sc->u_bad.p, nullptr, 0};
+    hipLaunchKernelGGL((count_scalar_kernel<NUCLEOTIDE, LIST_GLOBAL>), dim3((unsigned)r.num_cus * 2), dim3(256), 0, s, r.dev, d_q, nullptr, n,
+                       d_counts, nullptr, d_status, 1, L, ql);
+    HIP_CHECK(hipGetLastError());
+    return;
+  }
+  if (!two_phase) {
+    launch_count_ascii(r, d_q, nullptr, n, d_counts, nullptr, d_status, s, true, L);
+    return;
+  }
+  const unsigned nblk = (unsigned)r.num_cus * 8;  // both phases use this grid
+  const uint64_t per_block = ((n + (uint64_t)nblk * 256 - 1) / ((uint64_t)nblk * 256)) * 256;  // queries a block sees
+  if (sc->cap_q < per_block * nblk) {
+    HIP_CHECK(hipStreamSynchronize(s));
+    sc->q.alloc(per_block * nblk);
+    sc->cap_q = per_block * nblk;
+    sc->cap = 0;  // the nucleotide k-mer path re-allocates its three lists together
+  }
+  if (!sc->count.p) sc->count.alloc(nblk);
+  const QueryList ql{sc->q.p, sc->count.p, per_block, nullptr, nullptr, 0};
+  // Two queries in flight per lane (one: the same rate; four: 141 VGPRs, 10 % slower).  The second pass is a latency
+  // chain over a few per cent of the batch; running it for the first half of a batch on a side stream beside the first
+  // pass of the second half (event fork / join) was measured and costs more than it hides (12.7 -> 10.7 G present
+  // 12-mers/s, host path 0.83 -> 0.52 G queries/s).
+  hipLaunchKernelGGL(count_aa_kmer_probe_kernel<2>, dim3(nblk), dim3(256), 0, s, r.dev, d_q, n, (int)L, d_counts, d_status, ql);
+  hipLaunchKernelGGL((count_scalar_kernel<AMINO, LIST_BLOCK>), dim3(nblk), dim3(256), 0, s, r.dev, d_q, nullptr, n, d_counts, nullptr, d_status, 1, L, ql);
+  HIP_CHECK(hipGetLastError());
 }
 
 // pins a caller-owned host range for the duration of a batch so that H2D/D2H run as real async DMA

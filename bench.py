@@ -451,6 +451,17 @@ def main():
                 e1.record()
                 torch.cuda.synchronize()
             extra["ascii_resident_pack_plus_count"] = {"queries": na, "queries_per_s": na / (e0.elapsed_time(e1) / 5 * 1e-3)}
+            # the same through the one-call entry point (pack + packed kernels + the generic kernel over the list of
+            # queries with other letters, scratch in the replica)
+            c2 = torch.zeros(na, dtype=torch.int64, device=dev)
+            for rep in range(2):
+                e0.record()
+                for _ in range(5):
+                    ix.dev_count_ascii_uniform(asc.data_ptr(), na, L, c2.data_ptr(), None, stream, 0)
+                e1.record()
+                torch.cuda.synchronize()
+            assert bool(torch.equal(c2, counts[:na])), "awry_dev_count_ascii_uniform disagrees with pack + count"
+            extra["ascii_resident_one_call"] = {"queries": na, "queries_per_s": na / (e0.elapsed_time(e1) / 5 * 1e-3)}
             # the host boundary itself: ASCII + offsets in host memory -> awry_count_batch -> counts in host
             # memory; PCIe-inclusive, never the bench `value`
             h_q = asc.cpu().numpy()

@@ -175,9 +175,11 @@ int awry_dev_count_nt2_tally(awry_index_t *idx, int slot, const void *d_words, u
 /* generic path: ASCII queries + u64 offsets[n+1] -> counts[n], optional ranges[2n] (start,end) and status[n] bytes */
 int awry_dev_count_ascii(awry_index_t *idx, int slot, const void *d_qbytes, const void *d_qoff, uint64_t n,
                          void *d_counts, void *d_ranges, void *d_status, void *stream);
-/* n ASCII queries of `len` bytes each, back to back (no offsets) -> counts[n], optional status[n].  Amino k-mers of
- * 8..24 residues take a two-phase schedule of their own (one query per lane against the seed table and the text, the
- * generic kernel on the few it cannot decide); every other shape is the generic kernel reading query q at q * len */
+/* n ASCII queries of `len` bytes each, back to back (no offsets) -> counts[n], optional status[n].  Nucleotide
+ * indexes: packed on the device and served by the packed kernels (queries with letters outside ACGT are redone by the
+ * generic kernel).  Amino k-mers of 8..24 residues: a two-phase schedule of their own (one query per lane against the
+ * seed table and the text, the generic kernel on the few it cannot decide).  Every other shape: the generic kernel
+ * reading query q at q * len.  Scratch lives in the replica, per stream. */
 int awry_dev_count_ascii_uniform(awry_index_t *idx, int slot, const void *d_qbytes, uint64_t n, uint64_t len,
                                  void *d_counts, void *d_status, void *stream);
 /* exclusive scan of counts[n] -> hit_off[n+1] (d_scratch: awry_dev_scan_scratch_bytes(n) bytes) */

@@ -936,23 +936,49 @@ def test_amino_kmer_two_phase_schedule(oracle, L):
 
 
 def test_uniform_entry_point_on_a_nucleotide_index(oracle):
-    """awry_dev_count_ascii_uniform without the amino schedule: the generic kernel addressing query q at q * len"""
+    """awry_dev_count_ascii_uniform on a nucleotide index: packed on the device, packed kernels, the queries with letters
+    outside ACGT redone by the generic kernel over the pack kernel's list (which also names undefined ones); with the
+    accelerators off and without a seed table too; the generic kernel at q * len when the packed path does not apply"""
     import torch
     text, st, hd = synth.make_text(200000, 0, 5, 2, 0.03)
     ix = gpu_index(text, 0, 8, 0, st, hd)
     oi = oracle.OracleIndex.from_text(text, 0, 8, 0, st, hd)
     dev = torch.device("cuda", 0)
-    for L in (1, 5, 21, 40):
+    stream = torch.cuda.current_stream().cuda_stream
+    for L in (1, 5, 21, 32, 33, 40, 101):
         q2d = np.concatenate([synth.sampled_queries(text, 3000, L, L, True, 0), synth.random_queries(3000, L, 0, L + 1)])
         q2d[::97, L // 2] = ord("N")
+        q2d[5] = np.frombuffer(bytes(q2d[5]).lower(), np.uint8)
+        q2d[11, 0] = ord("R")
         qb = np.ascontiguousarray(q2d.reshape(-1))
         qo = np.arange(len(q2d) + 1, dtype=np.uint64) * np.uint64(L)
         want, _ = oi.parallel_count(qb, qo, 4)
         d_q = torch.from_numpy(np.concatenate([qb, np.zeros(16, dtype=np.uint8)])).to(dev)
+        for verify, k in ((2, -1), (-1, -1), (2, 0)):
+            ix.set_verify(verify)
+            ix.set_seed_kmer_len(k)
+            d_c = torch.full((len(q2d),), -1, dtype=torch.int64, device=dev)
+            d_s = torch.full((len(q2d),), 9, dtype=torch.uint8, device=dev)
+            ix.dev_count_ascii_uniform(d_q.data_ptr(), len(q2d), L, d_c.data_ptr(), d_s.data_ptr(), stream, 0)
+            d_c2 = torch.full((len(q2d),), -1, dtype=torch.int64, device=dev)
+            ix.dev_count_ascii_uniform(d_q.data_ptr(), len(q2d), L, d_c2.data_ptr(), None, stream, 0)
+            torch.cuda.synchronize()
+            assert np.array_equal(d_c.cpu().numpy().astype(np.uint64), want), (L, verify, k)
+            assert np.array_equal(d_c2.cpu().numpy().astype(np.uint64), want), (L, verify, k)
+            assert int(d_s.max()) == 0
+        ix.set_verify(2)
+        ix.set_seed_kmer_len(-1)
+        bad = q2d.copy()
+        bad[1234, L - 1] = ord("$")
+        d_b = torch.from_numpy(np.concatenate([bad.reshape(-1), np.zeros(16, dtype=np.uint8)])).to(dev)
         d_c = torch.zeros(len(q2d), dtype=torch.int64, device=dev)
-        ix.dev_count_ascii_uniform(d_q.data_ptr(), len(q2d), L, d_c.data_ptr(), None, torch.cuda.current_stream().cuda_stream, 0)
+        d_s = torch.zeros(len(q2d), dtype=torch.uint8, device=dev)
+        ix.dev_count_ascii_uniform(d_b.data_ptr(), len(q2d), L, d_c.data_ptr(), d_s.data_ptr(), stream, 0)
         torch.cuda.synchronize()
-        assert np.array_equal(d_c.cpu().numpy().astype(np.uint64), want), L
+        st_h = d_s.cpu().numpy()
+        assert np.nonzero(st_h)[0].tolist() == [1234] and st_h[1234] == 2
+        ok = np.arange(len(q2d)) != 1234
+        assert np.array_equal(d_c.cpu().numpy().astype(np.uint64)[ok], want[ok])
 
 
 def test_amino_kmer_schedule_on_a_large_batch(oracle):

@@ -785,14 +785,16 @@ void check_status(const ChunkBuffers& cb, uint64_t first_query) {
 // n ASCII queries of L bytes each, back to back: counts (and status) only.  Nucleotide: packed on the device and served by
 // the packed kernels.  Amino k-mers with a seed table: the two-phase schedule (count_aa_kmer_probe_kernel, then the
 // generic kernel on what it listed).  Anything else: the generic kernel reading its queries at q * L.
-void launch_count_ascii_uniform(Replica& r, const uint8_t* d_q, uint64_t n, uint64_t L, uint64_t* d_counts, uint8_t* d_status, hipStream_t s) {
+// d_ranges (optional): (start, end) / RS_* words per query for the locate pass, as launch_count_ascii writes them.
+void launch_count_ascii_uniform(Replica& r, const uint8_t* d_q, uint64_t n, uint64_t L, uint64_t* d_counts, uint8_t* d_status, hipStream_t s,
+                                uint64_t* d_ranges = nullptr) {
   if (n == 0) return;
   require(L >= 1, "query length must be at least 1");
   static const bool off = getenv("AWRY_AA_KMER") && !strcmp(getenv("AWRY_AA_KMER"), "0");
   const bool two_phase = !off && r.dev.alphabet == AMINO && L >= (uint64_t)AA_KMER_MIN && L <= (uint64_t)AA_KMER_MAX && r.seed_k >= 1 &&
                          (uint64_t)r.seed_k <= L && n < (1ull << 32);
   Replica::SurvScratch* sc = surv_scratch(r, s);
-  if (r.dev.alphabet == NUCLEOTIDE && r.dev.bwt_len < (1ull << 32) - 512 && L <= 4096 && n < (1ull << 32)) {
+  if (r.dev.alphabet == NUCLEOTIDE && !d_ranges && r.dev.bwt_len < (1ull << 32) - 512 && L <= 4096 && n < (1ull << 32)) {
     // the device half of the packed host path: pack 2 bits per letter, packed kernels, and the generic kernel over the
     // pack kernel's list for the queries with letters outside ACGT (it also writes their status)
     const uint64_t W = (L + 31) / 32;
@@ -814,7 +816,7 @@ void launch_count_ascii_uniform(Replica& r, const uint8_t* d_q, uint64_t n, uint
     return;
   }
   if (!two_phase) {
-    launch_count_ascii(r, d_q, nullptr, n, d_counts, nullptr, d_status, s, true, L);
+    launch_count_ascii(r, d_q, nullptr, n, d_counts, d_ranges, d_status, s, true, L);
     return;
   }
   const unsigned nblk = (unsigned)r.num_cus * 8;  // both phases use this grid
@@ -831,8 +833,8 @@ void launch_count_ascii_uniform(Replica& r, const uint8_t* d_q, uint64_t n, uint
   // chain over a few per cent of the batch; running it for the first half of a batch on a side stream beside the first
   // pass of the second half (event fork / join) was measured and costs more than it hides (12.7 -> 10.7 G present
   // 12-mers/s, host path 0.83 -> 0.52 G queries/s).
-  hipLaunchKernelGGL(count_aa_kmer_probe_kernel<2>, dim3(nblk), dim3(256), 0, s, r.dev, d_q, n, (int)L, d_counts, d_status, ql);
-  hipLaunchKernelGGL((count_scalar_kernel<AMINO, LIST_BLOCK>), dim3(nblk), dim3(256), 0, s, r.dev, d_q, nullptr, n, d_counts, nullptr, d_status, 1, L, ql);
+  hipLaunchKernelGGL(count_aa_kmer_probe_kernel<2>, dim3(nblk), dim3(256), 0, s, r.dev, d_q, n, (int)L, d_counts, d_ranges, d_status, ql);
+  hipLaunchKernelGGL((count_scalar_kernel<AMINO, LIST_BLOCK>), dim3(nblk), dim3(256), 0, s, r.dev, d_q, nullptr, n, d_counts, d_ranges, d_status, 1, L, ql);
   HIP_CHECK(hipGetLastError());
 }
 
@@ -1254,11 +1256,17 @@ void locate_shard_generic(Replica& r, const uint8_t* qbytes, const uint64_t* qof
 // per query, statuses checked in stage 2)
 void locate_shard_packed(Replica& r, const uint8_t* qbytes, const uint64_t* qoff, Shard sh, PackedPlan plan, bool want_gpos, LocateResult& out) {
   const bool generic = !plan.ok;
+  uint64_t ulen = 0;  // generic, every query of one length (amino k-mers): no offsets travel, the amino k-mer schedule counts
   if (generic) {
-    plan.ragged = true;  // offsets travel with the chunk
+    if (r.dev.alphabet == AMINO) {
+      const PackedPlan ap = plan_packed(qoff, sh);
+      if (ap.ok && !ap.ragged) ulen = ap.Lmax;
+    }
+    plan.ragged = ulen == 0;  // offsets travel with the chunk
     plan.Lmax = 1;
-    for (uint64_t i = sh.lo; i < sh.hi; i++)
-      if (qoff[i + 1] < qoff[i]) throw ArgError("query offsets must be non-decreasing");
+    if (!ulen)
+      for (uint64_t i = sh.lo; i < sh.hi; i++)
+        if (qoff[i + 1] < qoff[i]) throw ArgError("query offsets must be non-decreasing");
   }
   const uint64_t L = plan.Lmax, W = (L + 31) / 32;
   const std::vector<Shard> chunks = packed_chunks(qoff, sh, 1u << 20, 128ull << 20);
@@ -1319,7 +1327,8 @@ void locate_shard_packed(Replica& r, const uint8_t* qbytes, const uint64_t* qoff
     HIP_CHECK(hipMemsetAsync(ln.bad.p + 1, 0xFF, 8, s));
     const uint8_t* biased = reinterpret_cast<const uint8_t*>(reinterpret_cast<uintptr_t>(ln.ascii.p) - qoff[lo]);
     if (generic) {
-      launch_count_ascii(r, biased, ln.off.p, n, ln.counts.p, ln.rstart.p, ln.status.p, s, true);
+      if (ulen) launch_count_ascii_uniform(r, ln.ascii.p, n, ulen, ln.counts.p, ln.status.p, s, ln.rstart.p);
+      else launch_count_ascii(r, biased, ln.off.p, n, ln.counts.p, ln.rstart.p, ln.status.p, s, true);
       HIP_CHECK(hipMemcpyAsync(ln.h_status.p, ln.status.p, n, hipMemcpyDeviceToHost, s));
     } else {
       launch_pack_nt2(r, ln.ascii.p, plan.ragged ? ln.off.p : nullptr, qoff[lo], n, nbytes, (int)L, (int)W, ln.words.p,

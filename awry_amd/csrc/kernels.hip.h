@@ -369,7 +369,8 @@ constexpr int AA_KMER_VMULTI_LANES = 8;  //   when at least this many lanes of t
 
 template <int NQ>
 __global__ __launch_bounds__(256) void count_aa_kmer_probe_kernel(DevIndex ix, const uint8_t* __restrict__ ascii, uint64_t n, int L,
-                                                                  uint64_t* __restrict__ counts, uint8_t* __restrict__ status, QueryList ql) {
+                                                                  uint64_t* __restrict__ counts, uint64_t* __restrict__ ranges,
+                                                                  uint8_t* __restrict__ status, QueryList ql) {
   // per byte: bits 0..4 symbol index, bits 8..12 base-20 digit of a standard residue, bit 14 not a standard residue
   // (X and every other letter search as X, index 20), bit 15 undefined in the reference ('$', '#', bytes >= 0x80)
   __shared__ uint16_t lut[256];
@@ -392,9 +393,9 @@ __global__ __launch_bounds__(256) void count_aa_kmer_probe_kernel(DevIndex ix, c
   auto bytes_mask = [](int m) { return m >= 8 ? ~0ull : (m <= 0 ? 0ull : (1ull << (8 * m)) - 1); };
   const uint64_t m0 = bytes_mask(rem), m1 = bytes_mask(rem - 8), m2 = bytes_mask(rem - 16);
   auto ld8 = [](const uint8_t* p) { uint64_t v; __builtin_memcpy(&v, p, 8); return v; };
-  // how many of the candidates at text positions p[0 .. nc) have the query's first `rem` residues in front of them
+  // which of the candidates at text positions p[0 .. nc) have the query's first `rem` residues in front of them (bit c)
   auto candidates = [&](const uint32_t (&p)[AA_KMER_VMULTI], uint32_t nc, uint64_t j0, uint64_t j1, uint64_t j2) {
-    uint64_t found = 0;
+    uint32_t found = 0;
 #pragma unroll
     for (int c = 0; c < AA_KMER_VMULTI; c++) {
       if ((uint32_t)c >= nc || p[c] < (uint32_t)rem) continue;  // (the suffix starts too close to the text's beginning)
@@ -402,7 +403,7 @@ __global__ __launch_bounds__(256) void count_aa_kmer_probe_kernel(DevIndex ix, c
       uint64_t d = (ld8(t) ^ j0) & m0;
       if (rem > 8) d |= (ld8(t + 8) ^ j1) & m1;
       if (rem > 16) d |= (ld8(t + 16) ^ j2) & m2;
-      found += d ? 0ull : 1ull;
+      found |= d ? 0u : 1u << c;
     }
     return found;
   };
@@ -455,18 +456,22 @@ __global__ __launch_bounds__(256) void count_aa_kmer_probe_kernel(DevIndex ix, c
       if (qv[h] < n && !fl) ev[h] = seed[slot];
     }
     bool listed[NQ], vfy[NQ], multi[NQ];
-    uint64_t value[NQ], t0[NQ], t1[NQ], t2[NQ];
+    uint64_t value[NQ], rs[NQ], t0[NQ], t1[NQ], t2[NQ];  // rs: what the locate pass reads for the query (ranges[2q])
 #pragma unroll
     for (int h = 0; h < NQ; h++) {
       const SeedEntry e = ev[h];
       const uint32_t scnt = e.cnt & AA_SEED_CNT_SAT;
       listed[h] = vfy[h] = multi[h] = false;
       value[h] = 0;
+      rs[h] = (RS_PLAIN << RS_MODE_SHIFT) | 1ull;  // no hits
       t0[h] = t1[h] = t2[h] = 0;
       if (qv[h] >= n) continue;
       if (flags[h]) listed[h] = true;
       else if (scnt == 0u) value[h] = 0;
-      else if (rem == 0) { if (scnt == AA_SEED_CNT_SAT) listed[h] = true; else value[h] = scnt; }
+      else if (rem == 0) {  // the seed window is the whole query: the entry is the answer
+        if (scnt == AA_SEED_CNT_SAT) listed[h] = true;
+        else { value[h] = scnt; rs[h] = scnt == 1u && ix.seed_pos ? ((RS_SINGLE << RS_MODE_SHIFT) | e.sp) : ((RS_PLAIN << RS_MODE_SHIFT) | e.sp); }
+      }
       else if (scnt == 1u) {
         const int jn = rem - 1;  // the residue in front of the seed window must be BWT[row]
         const uint64_t wn = jn < 8 ? i0[h] : (jn < 16 ? i1[h] : i2[h]);
@@ -485,7 +490,10 @@ __global__ __launch_bounds__(256) void count_aa_kmer_probe_kernel(DevIndex ix, c
     }
 #pragma unroll
     for (int h = 0; h < NQ; h++) {
-      if (vfy[h]) value[h] = (((t0[h] ^ i0[h]) & m0) | ((t1[h] ^ i1[h]) & m1) | ((t2[h] ^ i2[h]) & m2)) ? 0ull : 1ull;
+      if (vfy[h]) {
+        value[h] = (((t0[h] ^ i0[h]) & m0) | ((t1[h] ^ i1[h]) & m1) | ((t2[h] ^ i2[h]) & m2)) ? 0ull : 1ull;
+        if (value[h]) rs[h] = (RS_SINGLE << RS_MODE_SHIFT) | ((uint64_t)ev[h].sp - (uint64_t)rem);
+      }
       // A handful of candidate rows, neighbours in the dense SA: each is compared with the text -- two dependent loads
       // the whole wave waits for, so a wave does it only when enough of its lanes need it (a batch of k-mers from the
       // text); the odd such lane of a random batch is listed, and the second pass works through those densely.
@@ -498,10 +506,13 @@ __global__ __launch_bounds__(256) void count_aa_kmer_probe_kernel(DevIndex ix, c
         uint32_t p[AA_KMER_VMULTI];
 #pragma unroll
         for (int c = 0; c < AA_KMER_VMULTI; c++) p[c] = (uint32_t)c < nc ? ix.dense_sa[sp + c] : 0u;
-        value[h] = candidates(p, nc, i0[h], i1[h], i2[h]);
+        const uint32_t mask = candidates(p, nc, i0[h], i1[h], i2[h]);
+        value[h] = (uint64_t)__popc(mask);
+        rs[h] = (RS_MULTI << RS_MODE_SHIFT) | (uint64_t)sp | ((uint64_t)rem << 32) | ((uint64_t)mask << 48);
       }
       if (qv[h] < n && !listed[h]) {
         counts[qv[h]] = value[h];
+        if (ranges) { ranges[2 * qv[h]] = rs[h]; ranges[2 * qv[h] + 1] = 0; }
         if (status) status[qv[h]] = Q_OK;
       }
       const uint64_t lm = __ballot(listed[h]);

@@ -895,6 +895,7 @@ def test_amino_kmer_two_phase_schedule(oracle, L):
     qb = np.ascontiguousarray(q2d.reshape(-1))
     qo = (np.arange(nq + 1, dtype=np.uint64) * np.uint64(L))
     want, _ = oi.parallel_count(qb, qo, 4)
+    want_loc = oi.parallel_locate(qb, qo, 4)[:3]
     assert (want > 1).sum() > 100 and (want == 1).sum() > 1000 and (want == 0).sum() > 1000
     dev = torch.device("cuda", 0)
     d_q = torch.from_numpy(np.concatenate([qb, np.zeros(16, dtype=np.uint8)])).to(dev)
@@ -914,6 +915,9 @@ def test_amino_kmer_two_phase_schedule(oracle, L):
             assert np.array_equal(d_c2.cpu().numpy().astype(np.uint64), want), (verify, k)
             assert int(d_s.max()) == 0
             assert np.array_equal(ix.parallel_count_csr(qb, qo), want), (verify, k)
+            if k in (-1, 3):  # parallel_locate: the same schedule is the count pass and hands the locate pass its range words
+                got = ix.parallel_locate_csr(qb, qo)
+                assert all(np.array_equal(x, y) for x, y in zip(got, want_loc)), (verify, k)
     # undefined bytes are named by the same pass that counts the rest
     bad = q2d.copy()
     bad[777, L // 2] = ord("$")
@@ -930,9 +934,10 @@ def test_amino_kmer_two_phase_schedule(oracle, L):
     ok = np.ones(nq, dtype=bool)
     ok[[777, 4242]] = False
     assert np.array_equal(d_c.cpu().numpy().astype(np.uint64)[ok], want[ok])
-    with pytest.raises(AwryError) as e:
-        ix.parallel_count_csr(np.ascontiguousarray(bad.reshape(-1)), qo)
-    assert e.value.code == ERR_INVALID_QUERY and "query 777" in str(e.value)
+    for fn in (ix.parallel_count_csr, ix.parallel_locate_csr):
+        with pytest.raises(AwryError) as e:
+            fn(np.ascontiguousarray(bad.reshape(-1)), qo)
+        assert e.value.code == ERR_INVALID_QUERY and "query 777" in str(e.value)
 
 
 def test_uniform_entry_point_on_a_nucleotide_index(oracle):

@@ -10,3 +10,9 @@ qb, qo = synth.fixed_to_csr(q2d)
 for rep in range(4):
     t = time.perf_counter(); c = ix.parallel_count_csr(qb, qo); dt = time.perf_counter() - t
     print("call %.1f ms" % (dt * 1e3), flush=True)
+# parallel_locate of 12-mers sampled from the text (equal lengths: the amino k-mer schedule is the count pass)
+q2d = synth.sampled_queries(text, 4_000_000, 12, 4, False, 1)
+qb, qo = synth.fixed_to_csr(q2d)
+for rep in range(4):
+    t = time.perf_counter(); off, g, p = ix.parallel_locate_csr(qb, qo); dt = time.perf_counter() - t
+    print("locate call %.1f ms, %d hits" % (dt * 1e3, len(g)), flush=True)

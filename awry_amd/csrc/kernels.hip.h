@@ -363,6 +363,8 @@ __global__ __launch_bounds__(256) void count_scalar_kernel(DevIndex ix, const ui
 // in the seed window, bytes the reference leaves undefined, entries with more rows, row seeds -- is listed per block
 // and redone by count_scalar_kernel<AMINO, LIST_BLOCK> on the same grid.  The generic kernel spends ~1 900 wave instructions
 // per 64 such queries, most of them offset and byte-stream bookkeeping; this pass executes 300-400 (counted in the ISA for L = 12).
+// ranges (optional): what the locate pass reads for a settled query, in the generic kernel's layout -- ranges[2q] = a row
+// interval's start or an RS_SINGLE / RS_MULTI word (verified text position / candidate rows + mask), ranges[2q + 1] = 0.
 constexpr int AA_KMER_MIN = 8, AA_KMER_MAX = 24;
 constexpr int AA_KMER_VMULTI = 4;        // seed ranges of up to this many rows are verified candidate by candidate
 constexpr int AA_KMER_VMULTI_LANES = 8;  //   when at least this many lanes of the wave hold one

@@ -104,6 +104,9 @@ def load_library():
     sig("awry_read_query_file", i32, cp, C.POINTER(u8p), C.POINTER(u64p), u64p)
     sig("awry_host_suffix_array", i32, vp, u64, u64p)
     sig("awry_symbol_index", u8, i32, u8)
+    sig("awry_host_pack_nt2", i32, vp, u64p, u64, u64, u64p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), u64p)
+    sig("awry_host_threads", i32)
+    sig("awry_host_memcpy", None, vp, vp, u64)
     sig("awry_dev_pack_nt2", i32, vp, i32, vp, u64, i32, vp, vp, vp)
     sig("awry_dev_count_nt2", i32, vp, i32, vp, u64, i32, vp, i32, vp)
     sig("awry_dev_count_nt2_tally", i32, vp, i32, vp, u64, i32, vp, i32, vp, vp)

@@ -16,8 +16,8 @@ LIBDIR = os.path.join(HERE, "lib")
 SO = os.path.join(LIBDIR, "libawry_hip.so")
 ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
 HIPCC = os.path.join(ROCM, "bin", "hipcc")
-SOURCES = ["awry_hip.hip", "sa_builder.hip", "host_index.cpp"]
-HEADERS = ["kernels.hip.h", "layout.h", "alphabet.h", "host_index.h", "sais.hpp", os.path.join("..", "..", "include", "awry_hip.h")]
+SOURCES = ["awry_hip.hip", "sa_builder.hip", "host_index.cpp", "host_pack.cpp"]
+HEADERS = ["kernels.hip.h", "layout.h", "alphabet.h", "host_index.h", "host_pack.h", "sais.hpp", os.path.join("..", "..", "include", "awry_hip.h")]
 
 
 def stale():
@@ -40,7 +40,9 @@ def build(force=False, verbose=False):
         [HIPCC, "--offload-arch=gfx950", "-march=x86-64-v3"] + common + ["-c", os.path.join(CSRC, "awry_hip.hip"), "-o", os.path.join(obj, "awry_hip.o")],
         [HIPCC, "--offload-arch=gfx950", "-march=x86-64-v3"] + common + ["-c", os.path.join(CSRC, "sa_builder.hip"), "-o", os.path.join(obj, "sa_builder.o")],
         ["g++", "-march=x86-64-v3"] + common + ["-c", os.path.join(CSRC, "host_index.cpp"), "-o", os.path.join(obj, "host_index.o")],
+        ["g++", "-march=x86-64-v3"] + common + ["-c", os.path.join(CSRC, "host_pack.cpp"), "-o", os.path.join(obj, "host_pack.o")],
         [HIPCC, "--offload-arch=gfx950", "-shared", "-o", SO, os.path.join(obj, "awry_hip.o"), os.path.join(obj, "sa_builder.o"), os.path.join(obj, "host_index.o"),
+         os.path.join(obj, "host_pack.o"),
          "-lpthread", "-Wl,-rpath," + os.path.join(ROCM, "lib")],
     ]
     for c in cmds:

@@ -23,6 +23,7 @@
 
 #include "alphabet.h"
 #include "host_index.h"
+#include "host_pack.h"
 #include "kernels.hip.h"
 #include "sais.hpp"
 
@@ -113,6 +114,15 @@ struct PackedLane {
   PinBuf<uint8_t> h_status;             //   and where the host reads it
   DevBuf<unsigned long long> bad;       // [0] number of listed queries, [1] first rejected query (index << 8 | status) or ~0
   unsigned long long* h_bad = nullptr;  // pinned copy of both
+  // host-packed path (count_shard_packed): persistent pinned staging, so that no caller memory is ever registered --
+  // packed words in, counts out, and the compact copy (indices, offsets, bytes) of the chunk's queries with other letters
+  PinBuf<uint64_t> h_words, h_boff;
+  PinBuf<uint32_t> h_counts32, h_lens, h_bq;  // counts cross PCIe as 32-bit words and are widened into counts_out
+  DevBuf<uint32_t> counts32;
+  PinBuf<uint8_t> h_bbytes;
+  DevBuf<uint8_t> bbytes;
+  DevBuf<uint64_t> boff;
+  uint64_t nbad = 0;
   uint64_t chunk_lo = 0, chunk_hi = 0;
   bool busy = false;
   ~PackedLane() {
@@ -132,6 +142,12 @@ struct LocateLane {
   DevBuf<unsigned long long> bad;              // [0] reads with bytes outside ACGT, [1] first rejected read (index << 8 | status) or ~0
   PinBuf<uint64_t> h_counts, h_gpos, h_meta;  // h_meta: [0] total hits of the chunk, [1..2] copy of `bad`
   PinBuf<awry_pos_t> h_pos;
+  // host-packed reads: pinned staging of the packed words / lengths and the compact copy of the reads with other letters
+  PinBuf<uint64_t> h_words, h_boff;
+  PinBuf<uint32_t> h_lens, h_bq;
+  PinBuf<uint8_t> h_bbytes;
+  DevBuf<uint8_t> bbytes;
+  DevBuf<uint64_t> boff;
   uint64_t lo = 0, hi = 0, total = 0;
   int stage = 0;                               // 0 idle, 1 count queued, 2 locate queued
   ~LocateLane() {
@@ -143,8 +159,9 @@ struct LocateLane {
 struct Replica {
   int device = -1;
   hipStream_t stream = nullptr;
-  hipStream_t lane_stream[2] = {nullptr, nullptr};  // the two pipeline lanes of the packed host path
-  PackedLane lanes[2];
+  static constexpr int NLANES = 3;
+  hipStream_t lane_stream[NLANES] = {nullptr, nullptr, nullptr};  // the pipeline lanes of the host paths (locate uses two)
+  PackedLane lanes[NLANES];
   LocateLane loc_lanes[2];
   std::mutex lane_mu;  // one packed host call at a time per replica
   // single-query calls (count_string, search_range): a pinned mailbox the generic kernel reads and writes in place --
@@ -875,15 +892,13 @@ PackedPlan plan_packed(const uint64_t* qoff, Shard sh) {
     mx = b;
   };
   uint64_t mn = ~0ull, mx = 0;
-  const unsigned T = n >= (2u << 20) ? std::min(8u, std::max(1u, std::thread::hardware_concurrency())) : 1;
-  if (T == 1) {
+  if (n < (1u << 18)) {
     scan(sh.lo, sh.hi, mn, mx);
-  } else {
-    std::vector<uint64_t> mns(T, ~0ull), mxs(T, 0);
-    std::vector<std::thread> th;
-    for (unsigned t = 0; t < T; t++) th.emplace_back([&, t] { scan(sh.lo + n * t / T, sh.lo + n * (t + 1) / T, mns[t], mxs[t]); });
-    for (auto& x : th) x.join();
-    for (unsigned t = 0; t < T; t++) { mn = std::min(mn, mns[t]); mx = std::max(mx, mxs[t]); }
+  } else {  // on the worker pool
+    const uint64_t grain = 1u << 16, pieces = (n + grain - 1) / grain;
+    std::vector<uint64_t> mns(pieces, ~0ull), mxs(pieces, 0);
+    HostPool::instance().run(pieces, [&](uint64_t t) { scan(sh.lo + t * grain, std::min(sh.hi, sh.lo + (t + 1) * grain), mns[t], mxs[t]); });
+    for (uint64_t t = 0; t < pieces; t++) { mn = std::min(mn, mns[t]); mx = std::max(mx, mxs[t]); }
   }
   if (mn == 0 || mx > 4096 || qoff[sh.hi] < qoff[sh.lo]) return plan;  // empty queries are the generic path's to reject
   plan.Lmax = mx;
@@ -916,6 +931,146 @@ void launch_count_nt2(Replica& r, const uint64_t* d_words, uint64_t n, int L, ui
                       unsigned long long* d_tally);
 void count_shard_generic(Replica& r, const uint8_t* qbytes, const uint64_t* qoff, Shard sh, uint64_t* counts_out);
 
+// The packed lanes with HOST packing -- the default path of parallel_count for nucleotide batches.  Per chunk: the pool
+// packs the ASCII into the lane's pinned staging (2 bits per letter: 8 B per 31-mer cross PCIe instead of 31 B, and no
+// caller memory is ever registered with the driver -- hipHostRegister of a fresh 150 MB batch cost more than its
+// transfer), H2D, packed kernels, D2H of the counts into pinned staging, and on retirement a pool memcpy into
+// counts_out (the first-touch faults of a fresh result array are taken by all threads).  The few queries with letters
+// outside ACGT travel as a compact CSR batch of their own and are redone on the device by the generic kernel
+// (LIST_COMPACT), overwriting their packed counts: results never depend on the path.
+// words != nullptr: the caller's k-mers are packed already (awry_count_packed_kmers): staged with a pool memcpy.
+void count_shard_hostpacked(Replica& r, const uint8_t* qbytes, const uint64_t* qoff, Shard sh, PackedPlan plan, uint64_t* counts_out,
+                            const uint64_t* words = nullptr) {
+  const uint64_t L = plan.Lmax, W = (L + 31) / 32;
+  static const bool trace = getenv("AWRY_TRACE_HOST") != nullptr;
+  static const uint64_t chunk_q = [] { const char* e = getenv("AWRY_HOST_CHUNK"); return e && atoll(e) > 0 ? (uint64_t)atoll(e) : (uint64_t)(1u << 20); }();
+  // full-size chunks, then a tail that halves down to 128 K queries: what cannot overlap anything is the GPU time of
+  // the last chunk, so it is kept small
+  std::vector<Shard> chunks;
+  for (uint64_t a = sh.lo; a < sh.hi;) {
+    const uint64_t rest = sh.hi - a;
+    uint64_t m = std::min(chunk_q, std::max<uint64_t>(rest / 2, std::min<uint64_t>(rest, 128u << 10)));
+    if (rest - m < (64u << 10)) m = rest;
+    if (!words && qoff[a + m] - qoff[a] > (256ull << 20)) {  // long reads: bound the bytes too
+      m = (uint64_t)(std::upper_bound(qoff + a, qoff + a + m + 1, qoff[a] + (256ull << 20)) - qoff) - 1 - a;
+      m = std::max<uint64_t>(m, 1);
+    }
+    chunks.push_back(Shard{a, a + m});
+    a += m;
+  }
+  uint64_t cap_q = 0;
+  for (Shard c : chunks) cap_q = std::max(cap_q, c.hi - c.lo);
+  auto now = [] { return std::chrono::steady_clock::now(); };
+  auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+  double t_pack = 0, t_wait = 0, t_out = 0, t_bad = 0;
+  std::lock_guard<std::mutex> lane_lock(r.lane_mu);
+  const auto t0 = now();
+  PackedLane* lanes = r.lanes;
+  uint64_t redone = 0;
+  auto retire = [&](PackedLane& ln) {
+    if (!ln.busy) return;
+    ln.busy = false;
+    auto a = now();
+    HIP_CHECK(hipEventSynchronize(ln.done));
+    auto b = now();
+    pool_widen_u32(counts_out + ln.chunk_lo, ln.h_counts32.p, ln.chunk_hi - ln.chunk_lo);
+    if (trace) { t_wait += ms(a, b); t_out += ms(b, now()); }
+    redone += ln.nbad;
+    if (ln.nbad && ln.h_bad[1] != ~0ull) {  // the lowest query of the chunk that the reference leaves undefined
+      ChunkBuffers cb;
+      cb.h_status.assign(1, (uint8_t)(ln.h_bad[1] & 0xFF));
+      check_status(cb, ln.chunk_lo + (ln.h_bad[1] >> 8));
+    }
+  };
+  struct Drain {  // every exit, normal or not, leaves the lanes idle
+    Replica& r;
+    ~Drain() {
+      for (int li = 0; li < Replica::NLANES; li++)
+        if (r.lanes[li].busy) { (void)hipStreamSynchronize(r.lane_stream[li]); r.lanes[li].busy = false; }
+    }
+  } drain{r};
+  const int nl = (int)std::min<size_t>(Replica::NLANES, chunks.size());
+  for (int li = 0; li < nl; li++) {
+    PackedLane& ln = lanes[li];
+    ln.s = r.lane_stream[li];
+    if (!ln.done) HIP_CHECK(hipEventCreateWithFlags(&ln.done, hipEventDisableTiming));
+    if (!ln.h_bad) HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&ln.h_bad), 16, hipHostMallocDefault));
+    ln.h_words.ensure(cap_q * W);
+    ln.h_counts32.ensure(cap_q);
+    if (ln.words.n < cap_q * W) ln.words.alloc(cap_q * W);
+    if (ln.counts.n < cap_q) ln.counts.alloc(cap_q);
+    if (ln.counts32.n < cap_q) ln.counts32.alloc(cap_q);
+    if (plan.ragged) { ln.h_lens.ensure(cap_q); if (ln.lens.n < cap_q) ln.lens.alloc(cap_q); }
+    if (ln.bad.n < 2) ln.bad.alloc(2);
+  }
+  const auto t1 = now();
+  std::vector<uint32_t> bad;
+  int which = 0;
+  for (Shard c : chunks) {
+    PackedLane& ln = lanes[which];
+    which = (which + 1) % nl;
+    retire(ln);
+    const uint64_t lo = c.lo, hi = c.hi, n = hi - lo;
+    ln.chunk_lo = lo;
+    ln.chunk_hi = hi;
+    auto a = now();
+    if (words) { pool_memcpy(ln.h_words.p, words + lo, n * 8); bad.clear(); }
+    else pack_nt2_host(qbytes + qoff[lo], qbytes + qoff[sh.hi], plan.ragged ? qoff : nullptr, lo, hi, L, ln.h_words.p, plan.ragged ? ln.h_lens.p : nullptr, bad);
+    auto b = now();
+    ln.nbad = bad.size();
+    HIP_CHECK(hipMemcpyAsync(ln.words.p, ln.h_words.p, n * W * 8, hipMemcpyHostToDevice, ln.s));
+    if (plan.ragged) HIP_CHECK(hipMemcpyAsync(ln.lens.p, ln.h_lens.p, n * 4, hipMemcpyHostToDevice, ln.s));
+    if (L <= 32 && !plan.ragged) launch_count_nt2(r, ln.words.p, n, (int)L, ln.counts.p, true, ln.s, nullptr);
+    else launch_count_nt2_long(r, ln.words.p, n, (int)L, ln.counts.p, nullptr, true, ln.s, plan.ragged ? ln.lens.p : nullptr);
+    if (ln.nbad) {  // compact copy of the listed queries: indices, offsets, bytes
+      const uint64_t nb = ln.nbad;
+      ln.h_bq.ensure(nb);
+      ln.h_boff.ensure(nb + 1);
+      uint64_t tot = 0;
+      for (uint64_t i = 0; i < nb; i++) {
+        const uint64_t q = lo + bad[i];
+        ln.h_bq.p[i] = bad[i];
+        ln.h_boff.p[i] = tot;
+        tot += qoff[q + 1] - qoff[q];
+      }
+      ln.h_boff.p[nb] = tot;
+      ln.h_bbytes.ensure(tot + 16);
+      HostPool::instance().run_ranges(nb, 4096, [&](uint64_t x, uint64_t y) {
+        for (uint64_t i = x; i < y; i++) {
+          const uint64_t q = lo + bad[i];
+          memcpy(ln.h_bbytes.p + ln.h_boff.p[i], qbytes + qoff[q], qoff[q + 1] - qoff[q]);
+        }
+      });
+      if (ln.bad_list.n < nb) ln.bad_list.alloc(nb + nb / 4 + 1024);
+      if (ln.boff.n < nb + 1) ln.boff.alloc(nb + nb / 4 + 1024);
+      if (ln.bbytes.n < tot + 16) ln.bbytes.alloc(tot + tot / 4 + 4096);
+      HIP_CHECK(hipMemcpyAsync(ln.bad_list.p, ln.h_bq.p, nb * 4, hipMemcpyHostToDevice, ln.s));
+      HIP_CHECK(hipMemcpyAsync(ln.boff.p, ln.h_boff.p, (nb + 1) * 8, hipMemcpyHostToDevice, ln.s));
+      HIP_CHECK(hipMemcpyAsync(ln.bbytes.p, ln.h_bbytes.p, tot, hipMemcpyHostToDevice, ln.s));
+      HIP_CHECK(hipMemsetAsync(ln.bad.p + 1, 0xFF, 8, ln.s));
+      const QueryList ql{ln.bad_list.p, nullptr, nb, nullptr, ln.bad.p + 1, 0};
+      hipLaunchKernelGGL((count_scalar_kernel<NUCLEOTIDE, LIST_COMPACT>), dim3(grid_for(r, nb, 256)), dim3(256), 0, ln.s, r.dev, ln.bbytes.p,
+                         ln.boff.p, n, ln.counts.p, nullptr, nullptr, 1, 0, ql);
+      HIP_CHECK(hipGetLastError());
+      HIP_CHECK(hipMemcpyAsync(ln.h_bad + 1, ln.bad.p + 1, 8, hipMemcpyDeviceToHost, ln.s));
+    }
+    hipLaunchKernelGGL(narrow_counts_kernel, dim3(grid_for(r, n, 1024)), dim3(256), 0, ln.s, ln.counts.p, ln.counts32.p, n);
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipMemcpyAsync(ln.h_counts32.p, ln.counts32.p, n * 4, hipMemcpyDeviceToHost, ln.s));
+    HIP_CHECK(hipEventRecord(ln.done, ln.s));
+    ln.busy = true;
+    if (trace) { t_pack += ms(a, b); t_bad += ms(b, now()); }
+  }
+  for (int k = 0; k < nl; k++) { retire(lanes[which]); which = (which + 1) % nl; }  // in chunk order
+  if (trace)
+    fprintf(stderr, "[awry] host-packed shard %llu queries%s L=%llu, %zu chunks, %u pool threads: lane setup %.2f ms, pipeline %.2f ms (%s %.2f, enqueue %.2f, "
+            "waiting for the GPU %.2f, copying counts out %.2f), %llu redone by the generic kernel\n",
+            (unsigned long long)(sh.hi - sh.lo), plan.ragged ? " (ragged)" : "", (unsigned long long)L, chunks.size(), HostPool::instance().threads(),
+            ms(t0, t1), ms(t1, now()), words ? "staging" : "host pack", t_pack, t_bad, t_wait, t_out, (unsigned long long)redone);
+}
+
+// the packed lanes with DEVICE packing (round 1's path, kept for A/B: AWRY_HOST_PACK=0): the chunk's ASCII crosses PCIe
+// from caller memory registered in place and pack_nt2_tile_kernel packs it
 void count_shard_packed(Replica& r, const uint8_t* qbytes, const uint64_t* qoff, Shard sh, PackedPlan plan, uint64_t* counts_out) {
   const uint64_t L = plan.Lmax;
   const int W = (int)((L + 31) / 32);
@@ -1109,7 +1264,9 @@ void count_shard(Replica& r, const uint8_t* qbytes, const uint64_t* qoff, Shard 
   if (getenv("AWRY_TRACE_HOST"))
     fprintf(stderr, "[awry] length scan %.2f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
   if (plan.ok) {
-    count_shard_packed(r, qbytes, qoff, sh, plan, counts_out);
+    static const bool dev_pack = getenv("AWRY_HOST_PACK") && !strcmp(getenv("AWRY_HOST_PACK"), "0");
+    if (dev_pack) count_shard_packed(r, qbytes, qoff, sh, plan, counts_out);
+    else count_shard_hostpacked(r, qbytes, qoff, sh, plan, counts_out);
     return;
   }
   if (!no_fast && sh.hi - sh.lo >= 4096) {
@@ -1134,20 +1291,6 @@ void count_shard_generic(Replica& r, const uint8_t* qbytes, const uint64_t* qoff
     HIP_CHECK(hipStreamSynchronize(r.stream));
     check_status(cb, c.lo);
   }
-}
-
-// memcpy for result-sized buffers: fresh destination pages fault on first touch, so large copies are cut over a few threads
-void par_memcpy(void* dst, const void* src, size_t bytes) {
-  // (from 4 MB on: a locate chunk's 8..16 MB slices used to go single-threaded and cost 16 of the 22 ms of a 4 M-read call)
-  const unsigned T = bytes >= (4u << 20) ? std::min(8u, std::max(1u, std::thread::hardware_concurrency())) : 1;
-  if (T == 1) { memcpy(dst, src, bytes); return; }
-  std::vector<std::thread> th;
-  const size_t per = ((bytes + T - 1) / T + 4095) & ~(size_t)4095;
-  for (unsigned t = 0; t < T; t++) {
-    const size_t lo = std::min(bytes, per * t), hi = std::min(bytes, per * (t + 1));
-    if (hi > lo) th.emplace_back([=] { memcpy(static_cast<char*>(dst) + lo, static_cast<const char*>(src) + lo, hi - lo); });
-  }
-  for (auto& x : th) x.join();
 }
 
 template <class T>
@@ -1190,23 +1333,26 @@ struct LocateResult {  // per shard, in query order
   MBuf<uint64_t> gpos;
   MBuf<awry_pos_t> pos;
   size_t total = 0;
+  bool want_pos = true;  // false: the caller passed hits_out == NULL -- (record, offset) pairs are neither computed nor moved
   void add_counts(const uint64_t* counts, uint64_t n) {  // next n queries of the shard
     for (uint64_t i = 0; i < n; i++) { running += counts[i]; off[filled + i + 1] = running; }
     filled += n;
   }
   void append(const uint64_t* g, const awry_pos_t* p, size_t n, bool want_gpos) {
     if (!n) return;
-    if (total + n > pos.cap && filled && filled < nq) {  // size the arrays for the whole shard from the hit rate so far
+    if (total + n > std::max(pos.cap, gpos.cap) && filled && filled < nq) {  // size the arrays for the whole shard from the hit rate so far
       const size_t est = (size_t)((double)(total + n) / (double)filled * (double)nq * 1.05) + 4096;
-      pos.grow(est);
+      if (want_pos) pos.grow(est);
       if (want_gpos) gpos.grow(est);
     }
-    pos.grow(total + n);
-    par_memcpy(pos.p + total, p, n * sizeof(awry_pos_t));
-    pos.used_bytes = (total + n) * sizeof(awry_pos_t);
+    if (want_pos) {
+      pos.grow(total + n);
+      pool_memcpy(pos.p + total, p, n * sizeof(awry_pos_t));
+      pos.used_bytes = (total + n) * sizeof(awry_pos_t);
+    }
     if (want_gpos) {
       gpos.grow(total + n);
-      par_memcpy(gpos.p + total, g, n * 8);
+      pool_memcpy(gpos.p + total, g, n * 8);
       gpos.used_bytes = (total + n) * 8;
     }
     total += n;
@@ -1215,7 +1361,7 @@ struct LocateResult {  // per shard, in query order
 
 // generic kernels, synchronous: any alphabet, ragged lengths, ambiguity codes
 void locate_chunk_generic(Replica& r, const uint8_t* qbytes, const uint64_t* qoff, Shard c, uint64_t* counts_out,
-                          std::vector<uint64_t>& gpos, std::vector<awry_pos_t>& pos) {
+                          std::vector<uint64_t>& gpos, std::vector<awry_pos_t>& pos, bool want_pos) {
   ChunkBuffers cb;
   const uint64_t n = c.hi - c.lo;
   run_count_chunk(r, cb, qbytes, qoff, c, true);
@@ -1227,11 +1373,11 @@ void locate_chunk_generic(Replica& r, const uint8_t* qbytes, const uint64_t* qof
   HIP_CHECK(hipStreamSynchronize(r.stream));
   check_status(cb, c.lo);
   gpos.resize(total);
-  pos.resize(total);
+  pos.resize(want_pos ? total : 0);
   if (total == 0) return;
-  DevBuf<uint64_t> d_gpos(total), d_pos(2 * total);
+  DevBuf<uint64_t> d_gpos(total), d_pos(want_pos ? 2 * total : 0);
   launch_locate(r, cb.ranges.p, 2, hit_off.p, n, total, d_gpos.p, d_pos.p, r.stream);
-  HIP_CHECK(hipMemcpyAsync(pos.data(), d_pos.p, total * 16, hipMemcpyDeviceToHost, r.stream));
+  if (want_pos) HIP_CHECK(hipMemcpyAsync(pos.data(), d_pos.p, total * 16, hipMemcpyDeviceToHost, r.stream));
   HIP_CHECK(hipMemcpyAsync(gpos.data(), d_gpos.p, total * 8, hipMemcpyDeviceToHost, r.stream));
   HIP_CHECK(hipStreamSynchronize(r.stream));
 }
@@ -1241,9 +1387,9 @@ void locate_shard_generic(Replica& r, const uint8_t* qbytes, const uint64_t* qof
   std::vector<awry_pos_t> p;
   for (Shard c : chunk_queries(qoff, sh.lo, sh.hi)) {
     counts.resize(c.hi - c.lo);
-    locate_chunk_generic(r, qbytes, qoff, c, counts.data(), g, p);
+    locate_chunk_generic(r, qbytes, qoff, c, counts.data(), g, p, out.want_pos);
     out.add_counts(counts.data(), c.hi - c.lo);
-    out.append(g.data(), p.data(), p.size(), want_gpos);
+    out.append(g.data(), p.data(), g.size(), want_gpos);
   }
 }
 
@@ -1255,7 +1401,7 @@ void locate_shard_generic(Replica& r, const uint8_t* qbytes, const uint64_t* qof
 // plan.ok == false: the same pipeline around the generic kernel (any alphabet, letters and lengths; ranges as two words
 // per query, statuses checked in stage 2)
 void locate_shard_packed(Replica& r, const uint8_t* qbytes, const uint64_t* qoff, Shard sh, PackedPlan plan, bool want_gpos, LocateResult& out) {
-  const bool generic = !plan.ok;
+  const bool generic = !plan.ok, want_pos = out.want_pos;
   uint64_t ulen = 0;  // generic, every query of one length (amino k-mers): no offsets travel, the amino k-mer schedule counts
   if (generic) {
     if (r.dev.alphabet == AMINO) {
@@ -1269,14 +1415,20 @@ void locate_shard_packed(Replica& r, const uint8_t* qbytes, const uint64_t* qoff
         if (qoff[i + 1] < qoff[i]) throw ArgError("query offsets must be non-decreasing");
   }
   const uint64_t L = plan.Lmax, W = (L + 31) / 32;
+  // nucleotide reads are packed on the HOST (2 bits per letter cross PCIe, nothing of the caller's is registered with the
+  // driver), as in count_shard_hostpacked; AWRY_HOST_PACK=0 keeps round 1's device packing for A/B
+  static const bool dev_pack = getenv("AWRY_HOST_PACK") && !strcmp(getenv("AWRY_HOST_PACK"), "0");
+  const bool hostpack = !generic && !dev_pack;
   const std::vector<Shard> chunks = packed_chunks(qoff, sh, 1u << 20, 128ull << 20);
   uint64_t cap = 0, cap_b = 0;
   for (Shard c : chunks) { cap = std::max(cap, c.hi - c.lo); cap_b = std::max(cap_b, qoff[c.hi] - qoff[c.lo]); }
   static const bool trace = getenv("AWRY_TRACE_HOST") != nullptr;
   const auto t0 = std::chrono::steady_clock::now();
   std::lock_guard<std::mutex> lane_lock(r.lane_mu);
-  HostPin pin_in(qbytes + qoff[sh.lo], qoff[sh.hi] - qoff[sh.lo]);
-  HostPin pin_off(plan.ragged ? qoff + sh.lo : nullptr, (sh.hi - sh.lo + 1) * 8);
+  HostPin pin_in(hostpack ? nullptr : qbytes + qoff[sh.lo], qoff[sh.hi] - qoff[sh.lo]);
+  HostPin pin_off(plan.ragged && !hostpack ? qoff + sh.lo : nullptr, (sh.hi - sh.lo + 1) * 8);
+  std::vector<uint32_t> bad;
+  double t_pack = 0;
   LocateLane* lanes = r.loc_lanes;
   double t_pin = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), t_wait_count = 0, t_wait_locate = 0, t_append = 0;
   auto timed = [&](double& acc, auto&& fn) {
@@ -1298,11 +1450,12 @@ void locate_shard_packed(Replica& r, const uint8_t* qbytes, const uint64_t* qoff
     LocateLane& ln = lanes[li];
     if (!ln.counted) HIP_CHECK(hipEventCreateWithFlags(&ln.counted, hipEventDisableTiming));
     if (!ln.located) HIP_CHECK(hipEventCreateWithFlags(&ln.located, hipEventDisableTiming));
-    if (ln.ascii.n < cap_b + 16) ln.ascii.alloc(cap_b + 16);
+    if (!hostpack && ln.ascii.n < cap_b + 16) ln.ascii.alloc(cap_b + 16);
     if (ln.words.n < cap * W) ln.words.alloc(cap * W);
-    if (plan.ragged && ln.off.n < cap + 1) ln.off.alloc(cap + 1);
+    if (plan.ragged && !hostpack && ln.off.n < cap + 1) ln.off.alloc(cap + 1);
     if (plan.ragged && ln.lens.n < cap) ln.lens.alloc(cap);
-    if (ln.bad_list.n < cap) ln.bad_list.alloc(cap);
+    if (!hostpack && ln.bad_list.n < cap) ln.bad_list.alloc(cap);
+    if (hostpack) { ln.h_words.ensure(cap * W); if (plan.ragged) ln.h_lens.ensure(cap); }
     if (ln.rstart.n < (generic ? 2 : 1) * cap) ln.rstart.alloc((generic ? 2 : 1) * cap);
     if (generic && ln.status.n < cap) ln.status.alloc(cap);
     if (generic) ln.h_status.ensure(cap);
@@ -1321,6 +1474,50 @@ void locate_shard_packed(Replica& r, const uint8_t* qbytes, const uint64_t* qoff
     ln.lo = lo;
     ln.hi = hi;
     const uint64_t nbytes = qoff[hi] - qoff[lo];
+    if (hostpack) {
+      timed(t_pack, [&] {
+        pack_nt2_host(qbytes + qoff[lo], qbytes + qoff[sh.hi], plan.ragged ? qoff : nullptr, lo, hi, L, ln.h_words.p, plan.ragged ? ln.h_lens.p : nullptr, bad);
+      });
+      HIP_CHECK(hipMemcpyAsync(ln.words.p, ln.h_words.p, n * W * 8, hipMemcpyHostToDevice, s));
+      if (plan.ragged) HIP_CHECK(hipMemcpyAsync(ln.lens.p, ln.h_lens.p, n * 4, hipMemcpyHostToDevice, s));
+      HIP_CHECK(hipMemsetAsync(ln.bad.p, 0, 8, s));
+      HIP_CHECK(hipMemsetAsync(ln.bad.p + 1, 0xFF, 8, s));
+      launch_count_nt2_long(r, ln.words.p, n, (int)L, ln.counts.p, ln.rstart.p, true, s, plan.ragged ? ln.lens.p : nullptr);
+      if (const uint64_t nb = bad.size()) {
+        // reads with other bytes (N, IUPAC codes ...): a compact CSR batch of their own, redone by the generic kernel, which
+        // overwrites their counts and range words (starts only, the packed kernels' layout) before the scan
+        ln.h_bq.ensure(nb);
+        ln.h_boff.ensure(nb + 1);
+        uint64_t tot = 0;
+        for (uint64_t i = 0; i < nb; i++) {
+          ln.h_bq.p[i] = bad[i];
+          ln.h_boff.p[i] = tot;
+          tot += qoff[lo + bad[i] + 1] - qoff[lo + bad[i]];
+        }
+        ln.h_boff.p[nb] = tot;
+        ln.h_bbytes.ensure(tot + 16);
+        HostPool::instance().run_ranges(nb, 4096, [&](uint64_t x, uint64_t y) {
+          for (uint64_t i = x; i < y; i++) memcpy(ln.h_bbytes.p + ln.h_boff.p[i], qbytes + qoff[lo + bad[i]], qoff[lo + bad[i] + 1] - qoff[lo + bad[i]]);
+        });
+        if (ln.bad_list.n < nb) ln.bad_list.alloc(nb + nb / 4 + 1024);
+        if (ln.boff.n < nb + 1) ln.boff.alloc(nb + nb / 4 + 1024);
+        if (ln.bbytes.n < tot + 16) ln.bbytes.alloc(tot + tot / 4 + 4096);
+        HIP_CHECK(hipMemcpyAsync(ln.bad_list.p, ln.h_bq.p, nb * 4, hipMemcpyHostToDevice, s));
+        HIP_CHECK(hipMemcpyAsync(ln.boff.p, ln.h_boff.p, (nb + 1) * 8, hipMemcpyHostToDevice, s));
+        HIP_CHECK(hipMemcpyAsync(ln.bbytes.p, ln.h_bbytes.p, tot, hipMemcpyHostToDevice, s));
+        const QueryList ql{ln.bad_list.p, nullptr, nb, nullptr, ln.bad.p + 1, 1};
+        hipLaunchKernelGGL((count_scalar_kernel<NUCLEOTIDE, LIST_COMPACT>), dim3(grid_for(r, nb, 256)), dim3(256), 0, s, r.dev, ln.bbytes.p, ln.boff.p, n,
+                           ln.counts.p, ln.rstart.p, nullptr, 1, 0, ql);
+        HIP_CHECK(hipGetLastError());
+      }
+      launch_scan(r, ln.counts.p, n, ln.hit_off.p, ln.scratch.p, s);
+      HIP_CHECK(hipMemcpyAsync(ln.h_meta.p, ln.hit_off.p + n, 8, hipMemcpyDeviceToHost, s));
+      HIP_CHECK(hipMemcpyAsync(ln.h_meta.p + 1, ln.bad.p, 16, hipMemcpyDeviceToHost, s));
+      HIP_CHECK(hipMemcpyAsync(ln.h_counts.p, ln.counts.p, n * 8, hipMemcpyDeviceToHost, s));
+      HIP_CHECK(hipEventRecord(ln.counted, s));
+      ln.stage = 1;
+      return;
+    }
     HIP_CHECK(hipMemcpyAsync(ln.ascii.p, qbytes + qoff[lo], nbytes, hipMemcpyHostToDevice, s));
     if (plan.ragged) HIP_CHECK(hipMemcpyAsync(ln.off.p, qoff + lo, (n + 1) * 8, hipMemcpyHostToDevice, s));
     HIP_CHECK(hipMemsetAsync(ln.bad.p, 0, 8, s));
@@ -1377,13 +1574,13 @@ void locate_shard_packed(Replica& r, const uint8_t* qbytes, const uint64_t* qoff
       // a hit-heavy chunk (repeats, N runs): the positions come back in pieces through the bounded staging, appended
       // here -- every earlier chunk has been appended already (stage 3 of chunk i - 2 runs before stage 1 of chunk i)
       if (ln.gpos.n < ln.total) ln.gpos.alloc(ln.total + ln.total / 4);
-      if (ln.pos.n < 2 * ln.total) ln.pos.alloc(2 * (ln.total + ln.total / 4));
-      ln.h_pos.ensure(STAGE_CAP);
+      if (want_pos && ln.pos.n < 2 * ln.total) ln.pos.alloc(2 * (ln.total + ln.total / 4));
+      if (want_pos) ln.h_pos.ensure(STAGE_CAP);
       if (want_gpos) ln.h_gpos.ensure(STAGE_CAP);
-      launch_locate(r, ln.rstart.p, generic ? 2 : 1, ln.hit_off.p, n, ln.total, ln.gpos.p, ln.pos.p, s);
+      launch_locate(r, ln.rstart.p, generic ? 2 : 1, ln.hit_off.p, n, ln.total, ln.gpos.p, want_pos ? ln.pos.p : nullptr, s);
       for (uint64_t at = 0; at < ln.total; at += STAGE_CAP) {
         const uint64_t m = std::min(STAGE_CAP, ln.total - at);
-        HIP_CHECK(hipMemcpyAsync(ln.h_pos.p, ln.pos.p + 2 * at, m * 16, hipMemcpyDeviceToHost, s));
+        if (want_pos) HIP_CHECK(hipMemcpyAsync(ln.h_pos.p, ln.pos.p + 2 * at, m * 16, hipMemcpyDeviceToHost, s));
         if (want_gpos) HIP_CHECK(hipMemcpyAsync(ln.h_gpos.p, ln.gpos.p + at, m * 8, hipMemcpyDeviceToHost, s));
         HIP_CHECK(hipStreamSynchronize(s));
         out.append(ln.h_gpos.p, ln.h_pos.p, m, want_gpos);
@@ -1393,11 +1590,11 @@ void locate_shard_packed(Replica& r, const uint8_t* qbytes, const uint64_t* qoff
     }
     if (ln.total) {
       if (ln.gpos.n < ln.total) ln.gpos.alloc(ln.total + ln.total / 4);
-      if (ln.pos.n < 2 * ln.total) ln.pos.alloc(2 * (ln.total + ln.total / 4));
-      ln.h_pos.ensure(ln.total);
+      if (want_pos && ln.pos.n < 2 * ln.total) ln.pos.alloc(2 * (ln.total + ln.total / 4));
+      if (want_pos) ln.h_pos.ensure(ln.total);
       if (want_gpos) ln.h_gpos.ensure(ln.total);
-      launch_locate(r, ln.rstart.p, generic ? 2 : 1, ln.hit_off.p, n, ln.total, ln.gpos.p, ln.pos.p, s);
-      HIP_CHECK(hipMemcpyAsync(ln.h_pos.p, ln.pos.p, ln.total * 16, hipMemcpyDeviceToHost, s));
+      launch_locate(r, ln.rstart.p, generic ? 2 : 1, ln.hit_off.p, n, ln.total, ln.gpos.p, want_pos ? ln.pos.p : nullptr, s);
+      if (want_pos) HIP_CHECK(hipMemcpyAsync(ln.h_pos.p, ln.pos.p, ln.total * 16, hipMemcpyDeviceToHost, s));
       if (want_gpos) HIP_CHECK(hipMemcpyAsync(ln.h_gpos.p, ln.gpos.p, ln.total * 8, hipMemcpyDeviceToHost, s));
     }
     HIP_CHECK(hipEventRecord(ln.located, s));
@@ -1423,9 +1620,9 @@ void locate_shard_packed(Replica& r, const uint8_t* qbytes, const uint64_t* qoff
   stage2(last);
   stage3(last);
   if (trace)
-    fprintf(stderr, "[awry] packed locate shard: %llu reads, %zu hits, %.2f ms (pin %.2f, waiting for counts %.2f, for positions %.2f, copying out %.2f)\n",
+    fprintf(stderr, "[awry] packed locate shard: %llu reads, %zu hits, %.2f ms (pin %.2f, host pack %.2f, waiting for counts %.2f, for positions %.2f, copying out %.2f)\n",
             (unsigned long long)(sh.hi - sh.lo), out.total, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(),
-            t_pin, t_wait_count, t_wait_locate, t_append);
+            t_pin, t_pack, t_wait_count, t_wait_locate, t_append);
 }
 
 void locate_shard(Replica& r, const uint8_t* qbytes, const uint64_t* qoff, Shard sh, bool want_gpos, LocateResult& out) {
@@ -1674,48 +1871,10 @@ int awry_count_packed_kmers(awry_index_t* idx, const uint64_t* words, uint64_t n
       HIP_CHECK(hipSetDevice(r.device));
       require(r.dev.alphabet == NUCLEOTIDE && r.dev.bwt_len < (1ull << 32) - 512, "packed k-mers need a nucleotide index with bwt_len < 2^32");
       if (sh.hi <= sh.lo) return;
-      std::lock_guard<std::mutex> lane_lock(r.lane_mu);
-      std::unique_ptr<HostPin> pin_out;  // pinned by a helper thread while the first chunk is on its way (as in count_shard_packed)
-      std::thread pin_out_thread([&] {
-        (void)hipSetDevice(r.device);
-        pin_out.reset(new HostPin(counts_out + sh.lo, (sh.hi - sh.lo) * 8));
-      });
-      struct Joiner {
-        std::thread& t;
-        ~Joiner() { if (t.joinable()) t.join(); }
-      } joiner{pin_out_thread};
-      HostPin pin_in(words + sh.lo, (sh.hi - sh.lo) * 8);
-      const uint64_t CH = 4u << 20;
-      PackedLane* lanes = r.lanes;
-      struct Drain {
-        Replica& r;
-        ~Drain() {
-          for (int li = 0; li < 2; li++)
-            if (r.lanes[li].busy) { (void)hipStreamSynchronize(r.lane_stream[li]); r.lanes[li].busy = false; }
-        }
-      } drain{r};
-      for (int li = 0; li < 2; li++) {
-        PackedLane& ln = lanes[li];
-        ln.s = r.lane_stream[li];
-        if (!ln.done) HIP_CHECK(hipEventCreateWithFlags(&ln.done, hipEventDisableTiming));
-        const uint64_t cap = std::min<uint64_t>(CH, sh.hi - sh.lo);
-        if (ln.words.n < cap) ln.words.alloc(cap);
-        if (ln.counts.n < cap) ln.counts.alloc(cap);
-      }
-      int which = 0;
-      for (uint64_t lo = sh.lo; lo < sh.hi; lo += CH, which ^= 1) {
-        PackedLane& ln = lanes[which];
-        if (ln.busy) { HIP_CHECK(hipEventSynchronize(ln.done)); ln.busy = false; }
-        const uint64_t m = std::min(sh.hi, lo + CH) - lo;
-        HIP_CHECK(hipMemcpyAsync(ln.words.p, words + lo, m * 8, hipMemcpyHostToDevice, ln.s));
-        launch_count_nt2(r, ln.words.p, m, L, ln.counts.p, true, ln.s, nullptr);
-        if (pin_out_thread.joinable()) pin_out_thread.join();
-        HIP_CHECK(hipMemcpyAsync(counts_out + lo, ln.counts.p, m * 8, hipMemcpyDeviceToHost, ln.s));
-        HIP_CHECK(hipEventRecord(ln.done, ln.s));
-        ln.busy = true;
-      }
-      for (int li = 0; li < 2; li++)
-        if (lanes[li].busy) { HIP_CHECK(hipEventSynchronize(lanes[li].done)); lanes[li].busy = false; }
+      PackedPlan plan;
+      plan.ok = true;
+      plan.Lmax = (uint64_t)L;
+      count_shard_hostpacked(r, nullptr, nullptr, sh, plan, counts_out, words);  // staged through the lanes' pinned buffers
     });
   });
 }
@@ -1723,10 +1882,11 @@ int awry_count_packed_kmers(awry_index_t* idx, const uint64_t* words, uint64_t n
 int awry_locate_batch(awry_index_t* idx, const uint8_t* qbytes, const uint64_t* qoff, uint64_t n, uint64_t** hit_off_out,
                       awry_pos_t** hits_out, uint64_t** global_pos_out) {
   return guarded([&] {
-    require(idx && qoff && hit_off_out && hits_out, "null argument");
+    require(idx && qoff && hit_off_out, "null argument");
     require(qbytes || qoff[n] == qoff[0], "null query bytes");
     const auto t0 = std::chrono::steady_clock::now();
     std::vector<LocateResult> res(std::max<size_t>(1, idx->reps.size()));
+    for (auto& x : res) x.want_pos = hits_out != nullptr;
     std::unique_ptr<uint64_t, decltype(&free)> off(malloc_array<uint64_t>(n + 1), &free);
     off.get()[0] = 0;
     {
@@ -1740,19 +1900,19 @@ int awry_locate_batch(awry_index_t* idx, const uint8_t* qbytes, const uint64_t* 
         for (uint64_t i = 1; i <= res[g].nq; i++) res[g].off[i] += total;
       total += res[g].total;
     }
-    if (res.size() == 1 && res[0].pos.p && (!global_pos_out || res[0].gpos.p)) {  // one replica: its arrays are the result
-      *hits_out = res[0].pos.release();
+    if (res.size() == 1 && (!hits_out || res[0].pos.p) && (!global_pos_out || res[0].gpos.p)) {  // one replica: its arrays are the result
+      if (hits_out) *hits_out = res[0].pos.release();
       if (global_pos_out) *global_pos_out = res[0].gpos.release();
     } else {
-      std::unique_ptr<awry_pos_t, decltype(&free)> hits(malloc_array<awry_pos_t>(total), &free);
+      std::unique_ptr<awry_pos_t, decltype(&free)> hits(hits_out ? malloc_array<awry_pos_t>(total) : nullptr, &free);
       std::unique_ptr<uint64_t, decltype(&free)> gp(global_pos_out ? malloc_array<uint64_t>(total) : nullptr, &free);
       uint64_t at = 0;
       for (auto& x : res) {
-        if (x.total) par_memcpy(hits.get() + at, x.pos.p, x.total * sizeof(awry_pos_t));
-        if (gp && x.total) par_memcpy(gp.get() + at, x.gpos.p, x.total * 8);
+        if (hits && x.total) pool_memcpy(hits.get() + at, x.pos.p, x.total * sizeof(awry_pos_t));
+        if (gp && x.total) pool_memcpy(gp.get() + at, x.gpos.p, x.total * 8);
         at += x.total;
       }
-      *hits_out = hits.release();
+      if (hits_out) *hits_out = hits.release();
       if (global_pos_out) *global_pos_out = gp.release();
     }
     *hit_off_out = off.release();
@@ -1956,6 +2116,25 @@ int awry_host_suffix_array(const uint8_t* text, uint64_t n, uint64_t* sa_out) {
   });
 }
 uint8_t awry_symbol_index(int alphabet, uint8_t ascii) { return (uint8_t)index_of_ascii(alphabet, ascii); }
+
+int awry_host_pack_nt2(const uint8_t* qbytes, const uint64_t* qoff, uint64_t n, uint64_t L, uint64_t* words_out, uint32_t* lens_out,
+                       uint32_t* bad_out, uint64_t* nbad_out) {
+  return guarded([&] {
+    require((qbytes && words_out && nbad_out) || n == 0, "null argument");
+    require(L >= 1 && L <= 4096, "packed query length out of range");
+    if (nbad_out) *nbad_out = 0;
+    if (n == 0) return;
+    if (qoff)
+      for (uint64_t i = 0; i < n; i++) require(qoff[i + 1] >= qoff[i] && qoff[i + 1] - qoff[i] >= 1 && qoff[i + 1] - qoff[i] <= L, "query length outside 1..L");
+    std::vector<uint32_t> bad;
+    const uint8_t* first = qbytes + (qoff ? qoff[0] : 0);
+    pack_nt2_host(first, qbytes + (qoff ? qoff[n] : n * L), qoff, 0, n, L, words_out, qoff ? lens_out : nullptr, bad);
+    *nbad_out = bad.size();
+    if (bad_out) std::copy(bad.begin(), bad.end(), bad_out);
+  });
+}
+int awry_host_threads(void) { return (int)HostPool::instance().threads(); }
+void awry_host_memcpy(void* dst, const void* src, uint64_t bytes) { pool_memcpy(dst, src, bytes); }
 
 // ---- device-resident API -----------------------------------------------------------------------------
 

@@ -1,0 +1,261 @@
+// host_pack.cpp -- persistent host worker pool + AVX2 ASCII -> 2-bit packer (see host_pack.h).
+#include "host_pack.h"
+
+#include <immintrin.h>
+#include <sched.h>
+
+#include <algorithm>
+#include <atomic>
+#include <condition_variable>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <exception>
+#include <mutex>
+#include <thread>
+
+namespace awry {
+
+unsigned effective_cpus() {
+  if (const char* e = getenv("AWRY_HOST_THREADS")) {
+    const int v = atoi(e);
+    if (v >= 1) return (unsigned)std::min(v, 256);
+  }
+  unsigned n = std::max(1u, std::thread::hardware_concurrency());
+  cpu_set_t set;
+  if (sched_getaffinity(0, sizeof(set), &set) == 0) n = std::max(1, CPU_COUNT(&set));
+  auto quota = [&](const char* path_quota, const char* path_period) {
+    FILE* f = fopen(path_quota, "r");
+    if (!f) return;
+    char a[64] = {0}, b[64] = {0};
+    const int got = fscanf(f, "%63s %63s", a, b);
+    fclose(f);
+    long long q = -1, p = 0;
+    if (path_period) {  // cgroup v1: two files
+      q = atoll(a);
+      if (FILE* g = fopen(path_period, "r")) {
+        if (fscanf(g, "%63s", b) == 1) p = atoll(b);
+        fclose(g);
+      }
+    } else if (got == 2 && strcmp(a, "max") != 0) {  // cgroup v2: "<quota> <period>"
+      q = atoll(a);
+      p = atoll(b);
+    }
+    if (q > 0 && p > 0) n = std::min<unsigned>(n, (unsigned)std::max<long long>(1, q / p));
+  };
+  quota("/sys/fs/cgroup/cpu.max", nullptr);
+  quota("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "/sys/fs/cgroup/cpu/cpu.cfs_period_us");
+  return std::max(1u, std::min(n, 64u));
+}
+
+struct HostPool::Impl {
+  std::vector<std::thread> workers;
+  std::mutex job_mu;  // one job at a time
+  std::mutex mu;
+  std::condition_variable cv_start, cv_done;
+  const std::function<void(uint64_t)>* fn = nullptr;
+  uint64_t n = 0;
+  std::atomic<uint64_t> next{0};
+  std::atomic<uint64_t> generation{0};
+  unsigned active = 0;  // workers that have not yet checked out of the current job
+  bool stop = false;
+  std::exception_ptr err;
+
+  void drain(const std::function<void(uint64_t)>& f, uint64_t total) {
+    for (;;) {
+      const uint64_t i = next.fetch_add(1, std::memory_order_relaxed);
+      if (i >= total) break;
+      try {
+        f(i);
+      } catch (...) {
+        std::lock_guard<std::mutex> lk(mu);
+        if (!err) err = std::current_exception();
+      }
+    }
+  }
+
+  void worker() {
+    uint64_t seen = 0;
+    for (;;) {
+      // a batch call issues jobs back to back: spin briefly before going to sleep on the condition variable
+      for (int spin = 0; spin < 4000 && generation.load(std::memory_order_acquire) == seen; spin++) _mm_pause();
+      std::unique_lock<std::mutex> lk(mu);
+      cv_start.wait(lk, [&] { return stop || generation.load(std::memory_order_acquire) != seen; });
+      if (stop) return;
+      seen = generation.load(std::memory_order_acquire);
+      const std::function<void(uint64_t)>* f = fn;
+      const uint64_t total = n;
+      lk.unlock();
+      drain(*f, total);
+      lk.lock();
+      if (--active == 0) cv_done.notify_one();
+    }
+  }
+};
+
+HostPool::HostPool() : impl_(new Impl) {
+  const unsigned t = effective_cpus();
+  for (unsigned i = 1; i < t; i++) impl_->workers.emplace_back([this] { impl_->worker(); });
+}
+
+HostPool::~HostPool() {
+  {
+    std::lock_guard<std::mutex> lk(impl_->mu);
+    impl_->stop = true;
+  }
+  impl_->cv_start.notify_all();
+  for (auto& w : impl_->workers) w.join();
+  delete impl_;
+}
+
+HostPool& HostPool::instance() {
+  static HostPool pool;
+  return pool;
+}
+
+unsigned HostPool::threads() const { return (unsigned)impl_->workers.size() + 1; }
+
+void HostPool::run(uint64_t n, const std::function<void(uint64_t)>& fn) {
+  if (n == 0) return;
+  Impl& p = *impl_;
+  if (n == 1 || p.workers.empty()) {
+    for (uint64_t i = 0; i < n; i++) fn(i);
+    return;
+  }
+  std::lock_guard<std::mutex> job(p.job_mu);
+  {
+    std::lock_guard<std::mutex> lk(p.mu);
+    p.fn = &fn;
+    p.n = n;
+    p.next.store(0, std::memory_order_relaxed);
+    p.active = (unsigned)p.workers.size();
+    p.err = nullptr;
+    p.generation.fetch_add(1, std::memory_order_release);
+  }
+  p.cv_start.notify_all();
+  p.drain(fn, n);
+  std::unique_lock<std::mutex> lk(p.mu);
+  p.cv_done.wait(lk, [&] { return p.active == 0; });
+  if (p.err) {
+    std::exception_ptr e = p.err;
+    p.err = nullptr;
+    lk.unlock();
+    std::rethrow_exception(e);
+  }
+}
+
+void HostPool::run_ranges(uint64_t n, uint64_t grain, const std::function<void(uint64_t, uint64_t)>& fn) {
+  if (n == 0) return;
+  grain = std::max<uint64_t>(1, grain);
+  const uint64_t pieces = (n + grain - 1) / grain;
+  run(pieces, [&](uint64_t i) { fn(i * grain, std::min(n, (i + 1) * grain)); });
+}
+
+void pool_memcpy(void* dst, const void* src, size_t bytes) {
+  if (bytes < (1u << 20)) {
+    memcpy(dst, src, bytes);
+    return;
+  }
+  HostPool::instance().run_ranges(bytes, 1u << 19, [&](uint64_t lo, uint64_t hi) {
+    memcpy(static_cast<char*>(dst) + lo, static_cast<const char*>(src) + lo, hi - lo);
+  });
+}
+
+void pool_widen_u32(uint64_t* dst, const uint32_t* src, uint64_t n) {
+  // streaming stores: the result array is written once and not read here, so no line of it is fetched first
+  auto piece = [&](uint64_t lo, uint64_t hi) {
+    uint64_t i = lo;
+    for (; i < hi && (reinterpret_cast<uintptr_t>(dst + i) & 31); i++) dst[i] = src[i];
+    for (; i + 4 <= hi; i += 4)
+      _mm256_stream_si256(reinterpret_cast<__m256i*>(dst + i), _mm256_cvtepu32_epi64(_mm_loadu_si128(reinterpret_cast<const __m128i*>(src + i))));
+    for (; i < hi; i++) dst[i] = src[i];
+    _mm_sfence();
+  };
+  if (n < (1u << 17)) { piece(0, n); return; }
+  HostPool::instance().run_ranges(n, 1u << 16, piece);
+}
+
+namespace {
+
+// up to 32 letters at p -> 64 bits; *ok is cleared when one of the first m bytes is not in ACGTacgt.
+// Two 16-entry tables indexed by the low nibble of the case-folded byte (A x1, C x3, T x4, G x7): the letter that
+// nibble stands for -- the byte is valid iff it IS that letter (pshufb yields 0 for bytes >= 0x80, which then differ) --
+// and its 2-bit code A0 C1 G2 T3.
+inline uint64_t pack32(const uint8_t* p, int m, bool* ok) {
+  const __m256i x = _mm256_loadu_si256(reinterpret_cast<const __m256i*>(p));
+  const __m256i c = _mm256_and_si256(x, _mm256_set1_epi8((char)0xDF));  // upper-case; bytes >= 0x80 stay >= 0x80
+  const __m256i letter = _mm256_setr_epi8(-1, 'A', -1, 'C', 'T', -1, -1, 'G', -1, -1, -1, -1, -1, -1, -1, -1,
+                                          -1, 'A', -1, 'C', 'T', -1, -1, 'G', -1, -1, -1, -1, -1, -1, -1, -1);
+  const __m256i code = _mm256_setr_epi8(0, 0, 0, 1, 3, 0, 0, 2, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 3, 0, 0, 2, 0, 0, 0, 0, 0, 0, 0, 0);
+  const uint32_t vm = (uint32_t)_mm256_movemask_epi8(_mm256_cmpeq_epi8(_mm256_shuffle_epi8(letter, c), c));
+  const uint32_t need = m >= 32 ? ~0u : ((1u << m) - 1u);
+  if ((vm & need) != need) *ok = false;
+  const __m256i y = _mm256_shuffle_epi8(code, c);
+  const __m256i t = _mm256_maddubs_epi16(y, _mm256_set1_epi16(0x0401));  // b0 + 4 b1: 4 bits per 16-bit lane
+  const __m256i u = _mm256_madd_epi16(t, _mm256_set1_epi32(0x00100001));  // w0 + 16 w1: 8 bits per 32-bit lane
+  const __m256i s = _mm256_shuffle_epi8(u, _mm256_setr_epi8(0, 4, 8, 12, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1,
+                                                            0, 4, 8, 12, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1));
+  const __m128i lo = _mm256_castsi256_si128(s), hi = _mm256_extracti128_si256(s, 1);
+  const uint64_t w = (uint64_t)_mm_cvtsi128_si64(_mm_unpacklo_epi32(lo, hi));
+  return m >= 32 ? w : (w & ((1ull << (2 * m)) - 1));
+}
+
+// one query of `len` letters at p -> W words; returns false when it holds a byte outside ACGTacgt
+inline bool pack_query(const uint8_t* p, uint64_t len, const uint8_t* end, uint64_t* out, uint64_t W) {
+  bool ok = true;
+  uint64_t k = 0;
+  for (uint64_t j = 0; j < len; j += 32, k++) {
+    const int m = (int)std::min<uint64_t>(32, len - j);
+    if (p + j + 32 <= end) {
+      _mm_stream_si64(reinterpret_cast<long long*>(out + k), (long long)pack32(p + j, m, &ok));
+    } else {  // the last bytes of the buffer: a padded copy
+      alignas(32) uint8_t tmp[32];
+      memset(tmp, 'A', 32);
+      memcpy(tmp, p + j, (size_t)m);
+      out[k] = pack32(tmp, m, &ok);
+    }
+  }
+  for (; k < W; k++) out[k] = 0;
+  return ok;
+}
+
+}  // namespace
+
+void pack_nt2_host(const uint8_t* ascii, const uint8_t* ascii_end, const uint64_t* off, uint64_t lo, uint64_t hi, uint64_t L,
+                   uint64_t* words, uint32_t* lens, std::vector<uint32_t>& bad) {
+  const uint64_t n = hi - lo, W = (L + 31) / 32;
+  bad.clear();
+  if (n == 0) return;
+  std::mutex bad_mu;
+  const uint64_t base = off ? off[lo] : 0;
+  HostPool::instance().run_ranges(n, 8192, [&](uint64_t a, uint64_t b) {
+    uint32_t local[64];
+    int nl = 0;
+    auto flush = [&] {
+      std::lock_guard<std::mutex> lk(bad_mu);
+      bad.insert(bad.end(), local, local + nl);
+      nl = 0;
+    };
+    if (!off && L <= 32) {  // k-mers: one load, one word per query
+      const uint8_t* p = ascii + a * L;
+      const int m = (int)L;
+      for (uint64_t q = a; q < b; q++, p += L) {
+        bool ok = true;
+        if (p + 32 <= ascii_end) _mm_stream_si64(reinterpret_cast<long long*>(words + q), (long long)pack32(p, m, &ok));  // written once, read by the DMA engine
+        else ok = pack_query(p, L, ascii_end, words + q, 1);
+        if (!ok) { local[nl++] = (uint32_t)q; if (nl == 64) flush(); }
+      }
+    } else {
+      for (uint64_t q = a; q < b; q++) {
+        const uint64_t s = off ? off[lo + q] - base : q * L, len = off ? off[lo + q + 1] - off[lo + q] : L;
+        if (lens) lens[q] = (uint32_t)len;
+        if (!pack_query(ascii + s, len, ascii_end, words + q * W, W)) { local[nl++] = (uint32_t)q; if (nl == 64) flush(); }
+      }
+    }
+    if (nl) flush();
+    _mm_sfence();
+  });
+  if (bad.size() > 1) std::sort(bad.begin(), bad.end());
+}
+
+}  // namespace awry

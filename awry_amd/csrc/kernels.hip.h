@@ -192,7 +192,10 @@ __device__ __forceinline__ bool text_equals_query(const uint8_t* __restrict__ te
 // second phase of count_aa_kmer_probe_kernel.  LIST_GLOBAL: only the *ql.total queries of one device-wide list, in any
 // order -- the reads of a packed nucleotide chunk that hold letters outside ACGT, redone in place; the first query
 // (lowest index) with a non-zero status is reported through ql.first_bad as (index << 8 | status).
-enum { LIST_NONE = 0, LIST_BLOCK = 1, LIST_GLOBAL = 2 };
+// LIST_COMPACT: the ql.cap listed queries travel as a CSR batch of their own -- entry `it` is bytes [off[it], off[it + 1])
+// of ascii and answers for query ql.q[it] -- the form in which the host-packed paths hand over the few queries of a
+// chunk that hold letters outside ACGT (only those bytes cross PCIe); first_bad as for LIST_GLOBAL.
+enum { LIST_NONE = 0, LIST_BLOCK = 1, LIST_GLOBAL = 2, LIST_COMPACT = 3 };
 struct QueryList {
   uint32_t* q;                      // query indices; LIST_BLOCK: block b owns slots [b * cap, (b + 1) * cap)
   uint32_t* count;                  // LIST_BLOCK: listed queries per block
@@ -212,11 +215,12 @@ __global__ __launch_bounds__(256) void count_scalar_kernel(DevIndex ix, const ui
   lut[threadIdx.x] = (uint8_t)(threadIdx.x >= 128 ? 0xFF : index_of_ascii(A, (uint8_t)threadIdx.x));
   __syncthreads();
   const uint64_t stride = LIST == LIST_BLOCK ? blockDim.x : (uint64_t)gridDim.x * blockDim.x;
-  const uint64_t todo = LIST == LIST_BLOCK ? ql.count[blockIdx.x] : (LIST == LIST_GLOBAL ? (uint64_t)*ql.total : n);
+  const uint64_t todo = LIST == LIST_BLOCK ? ql.count[blockIdx.x] : (LIST == LIST_GLOBAL ? (uint64_t)*ql.total : (LIST == LIST_COMPACT ? ql.cap : n));
   const uint8_t* const ascii_bytes = ascii;
   for (uint64_t it = LIST == LIST_BLOCK ? threadIdx.x : (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; it < todo; it += stride) {
-    const uint64_t q = LIST == LIST_BLOCK ? ql.q[(uint64_t)blockIdx.x * ql.cap + it] : (LIST == LIST_GLOBAL ? ql.q[it] : it);
-    const uint64_t b = ulen ? q * ulen : off[q], e = ulen ? b + ulen : off[q + 1];
+    const uint64_t q = LIST == LIST_BLOCK ? ql.q[(uint64_t)blockIdx.x * ql.cap + it] : (LIST == LIST_GLOBAL || LIST == LIST_COMPACT ? ql.q[it] : it);
+    const uint64_t b = LIST == LIST_COMPACT ? off[it] : (ulen ? q * ulen : off[q]);
+    const uint64_t e = LIST == LIST_COMPACT ? off[it + 1] : (ulen ? b + ulen : off[q + 1]);
     ByteStream ascii(ascii_bytes);  // shadows the pointer: same indexing, 8 bytes per load
     uint8_t st = e > b ? Q_OK : Q_EMPTY;
     if (A == NUCLEOTIDE) {  // eight bytes at a time: any byte >= 0x80, any '$' or '#'
@@ -338,7 +342,7 @@ __global__ __launch_bounds__(256) void count_scalar_kernel(DevIndex ix, const ui
         step_scalar<A>(ix, sp, ep, lut[ascii[i]]);
       }
     }
-    const bool starts_only = LIST == LIST_GLOBAL && ql.range_stride == 1;
+    const bool starts_only = (LIST == LIST_GLOBAL || LIST == LIST_COMPACT) && ql.range_stride == 1;
     if (verified) {
       counts[q] = vcount;
       if (ranges) { if (starts_only) ranges[q] = vrs; else { ranges[2 * q] = vrs; ranges[2 * q + 1] = 0; } }
@@ -347,7 +351,7 @@ __global__ __launch_bounds__(256) void count_scalar_kernel(DevIndex ix, const ui
       if (ranges) { if (starts_only) ranges[q] = sp; else { ranges[2 * q] = sp; ranges[2 * q + 1] = ep; } }
     }
     if (status) status[q] = st;
-    if (LIST == LIST_GLOBAL && ql.first_bad && st != Q_OK) atomicMin(ql.first_bad, ((unsigned long long)q << 8) | st);
+    if ((LIST == LIST_GLOBAL || LIST == LIST_COMPACT) && ql.first_bad && st != Q_OK) atomicMin(ql.first_bad, ((unsigned long long)q << 8) | st);
   }
 }
 
@@ -528,6 +532,12 @@ __global__ __launch_bounds__(256) void count_aa_kmer_probe_kernel(DevIndex ix, c
   }
   __syncthreads();
   if (threadIdx.x == 0) ql.count[blockIdx.x] = s_count;
+}
+
+// counts as 32-bit words for the trip over PCIe (host-packed paths: a count is < bwt_len < 2^32 there)
+__global__ __launch_bounds__(256) void narrow_counts_kernel(const uint64_t* __restrict__ in, uint32_t* __restrict__ out, uint64_t n) {
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = (uint32_t)in[i];
 }
 
 // one step / one backstep / one initial range for the scalar conveniences of the C ABI

@@ -300,18 +300,27 @@ class FmIndex:
         return LocalizedSequencePosition(int(p.seq_idx), int(p.local_pos))
 
     # ------------------------------------------------------------------ batch queries
-    def parallel_count_csr(self, qbytes: np.ndarray, qoff: np.ndarray) -> np.ndarray:
+    def parallel_count_csr(self, qbytes: np.ndarray, qoff: np.ndarray, out: Optional[np.ndarray] = None) -> np.ndarray:
+        """counts of the CSR batch in input order; `out` (uint64[n], contiguous) is filled and returned when given -- the
+        C ABI's counts_out is caller-owned, and a caller that reuses its result array spares the batch the first-touch
+        page faults of a fresh one"""
         qb = np.ascontiguousarray(qbytes, dtype=np.uint8)
         qo = np.ascontiguousarray(qoff, dtype=np.uint64)
         n = len(qo) - 1
-        out = np.zeros(n, dtype=np.uint64)
+        if out is None:
+            out = np.empty(n, dtype=np.uint64)
+        elif out.dtype != np.uint64 or out.shape != (n,) or not out.flags.c_contiguous:
+            raise ValueError("out must be a contiguous uint64 array with one entry per query")
         _check(self._L.awry_count_batch(self._h, qb.ctypes.data, qo.ctypes.data_as(_u64p), n, out.ctypes.data_as(_u64p)))
         return out
 
-    def parallel_count_packed(self, words: np.ndarray, L: int) -> np.ndarray:
+    def parallel_count_packed(self, words: np.ndarray, L: int, out: Optional[np.ndarray] = None) -> np.ndarray:
         """k-mers already packed 2 bits per letter (letter j of a k-mer in bits [2j, 2j+2) of its uint64, A0 C1 G2 T3)"""
         w = np.ascontiguousarray(words, dtype=np.uint64)
-        out = np.zeros(len(w), dtype=np.uint64)
+        if out is None:
+            out = np.empty(len(w), dtype=np.uint64)
+        elif out.dtype != np.uint64 or out.shape != (len(w),) or not out.flags.c_contiguous:
+            raise ValueError("out must be a contiguous uint64 array with one entry per query")
         _check(self._L.awry_count_packed_kmers(self._h, w.ctypes.data_as(_u64p), len(w), L, out.ctypes.data_as(_u64p)))
         return out
 
@@ -319,17 +328,19 @@ class FmIndex:
         """src/fm_index.rs:455-460: counts in input order"""
         return self.parallel_count_csr(*pack_queries(queries))
 
-    def parallel_locate_csr(self, qbytes: np.ndarray, qoff: np.ndarray):
-        """-> (hit_off uint64[n+1], global_pos uint64[total], pos uint64[total, 2])"""
+    def parallel_locate_csr(self, qbytes: np.ndarray, qoff: np.ndarray, want_pos: bool = True):
+        """-> (hit_off uint64[n+1], global_pos uint64[total], pos uint64[total, 2]); want_pos=False passes hits_out = NULL
+        (text positions only: 8 B per hit cross PCIe instead of 24) and returns an empty pos"""
         qb = np.ascontiguousarray(qbytes, dtype=np.uint8)
         qo = np.ascontiguousarray(qoff, dtype=np.uint64)
         n = len(qo) - 1
         off, hits, gp = _u64p(), C.POINTER(_lib.Pos)(), _u64p()
-        _check(self._L.awry_locate_batch(self._h, qb.ctypes.data, qo.ctypes.data_as(_u64p), n, C.byref(off), C.byref(hits), C.byref(gp)))
+        _check(self._L.awry_locate_batch(self._h, qb.ctypes.data, qo.ctypes.data_as(_u64p), n, C.byref(off),
+                                         C.byref(hits) if want_pos else None, C.byref(gp)))
         offs = _adopt(self._L, off, n + 1, np.uint64)
         tot = int(offs[-1])
         g = _adopt(self._L, gp, tot, np.uint64)
-        p = _adopt(self._L, hits, 2 * tot, np.uint64).reshape(-1, 2)
+        p = _adopt(self._L, hits, 2 * tot, np.uint64).reshape(-1, 2) if want_pos else np.zeros((0, 2), np.uint64)
         return offs, g, p
 
     def parallel_locate(self, queries: Iterable) -> List[List[LocalizedSequencePosition]]:

@@ -175,17 +175,24 @@ def locate_benchmark(ix, text, torch, dev, stream, n_reads, read_len, oi=None, c
     # the host boundary (parallel_locate: ASCII reads in host memory -> offsets + positions in host memory), PCIe-inclusive
     nh_reads = min(n_reads, 4_000_000)
     qb, qo = synth.fixed_to_csr(reads[:nh_reads])
-    times = []
+    times, times_g = [], []
     for rep in range(4):
         tp = time.perf_counter()
         hoff, hg, hp = ix.parallel_locate_csr(qb, qo)
         times.append(time.perf_counter() - tp)
+        del hp
+        tp = time.perf_counter()
+        hoff2, hg2, _ = ix.parallel_locate_csr(qb, qo, want_pos=False)
+        times_g.append(time.perf_counter() - tp)
     nhh = int(hoff[-1])
     assert np.array_equal(hg, ref[:nhh]), "host-boundary locate differs from the device-resident pipeline"
-    dt = sorted(times[1:])[1]
+    assert np.array_equal(hoff2, hoff) and np.array_equal(hg2, hg)
+    dt, dtg = sorted(times[1:])[1], sorted(times_g[1:])[1]
     out["host_boundary_end_to_end"] = {"reads": nh_reads, "hits": nhh, "ms": dt * 1e3, "reads_per_s": nh_reads / dt,
-                                       "note": "PCIe-inclusive, through the Python mirror, median of 3 after 1 warm-up"}
-    del hoff, hg, hp
+                                       "positions_only_reads_per_s": nh_reads / dtg,
+                                       "note": "awry_locate_batch, PCIe-inclusive, through the Python mirror, median of 3 after 1 warm-up; reads packed on "
+                                               "the host; positions_only passes hits_out = NULL (8 B per hit back instead of 24)"}
+    del hoff, hg, hoff2, hg2
     if oi is not None:
         ns = min(n_reads, 200_000)
         qb, qo = synth.fixed_to_csr(reads[:ns])
@@ -466,15 +473,30 @@ def main():
             # memory; PCIe-inclusive, never the bench `value`
             h_q = asc.cpu().numpy()
             h_off = np.arange(na + 1, dtype=np.uint64) * np.uint64(L)
-            times = []
-            for rep in range(6):
-                tp = time.perf_counter()
-                h_counts = ix.parallel_count_csr(h_q, h_off)
-                times.append(time.perf_counter() - tp)
-            med = sorted(times[1:])[len(times[1:]) // 2]
+
+            def host_median(fn, reps=8):
+                ts = []
+                for _ in range(reps):
+                    tp = time.perf_counter()
+                    fn()
+                    ts.append(time.perf_counter() - tp)
+                return sorted(ts[1:])[len(ts[1:]) // 2]
+
+            h_counts = np.zeros(na, dtype=np.uint64)  # caller-owned counts_out, reused from call to call
+            med = host_median(lambda: ix.parallel_count_csr(h_q, h_off, h_counts))
             assert np.array_equal(h_counts, counts[:na].cpu().numpy().view(np.uint64))
-            extra["host_boundary_end_to_end"] = {"queries": na, "queries_per_s": na / med, "ms": med * 1e3,
-                                                 "host_in_GBs": h_q.nbytes / med / 1e9, "note": "PCIe-inclusive, median of 5 after 1 warm-up"}
+            med_fresh = host_median(lambda: ix.parallel_count_csr(h_q, h_off))
+            h_words = batches[0][:na].cpu().numpy().view(np.uint64)
+            med_packed = host_median(lambda: ix.parallel_count_packed(h_words, L, h_counts))
+            assert np.array_equal(h_counts, counts[:na].cpu().numpy().view(np.uint64))
+            extra["host_boundary_end_to_end"] = {
+                "queries": na, "queries_per_s": na / med, "ms": med * 1e3, "host_in_GBs": h_q.nbytes / med / 1e9,
+                "fresh_result_array_queries_per_s": na / med_fresh, "caller_packed_kmers_queries_per_s": na / med_packed,
+                "host_threads": awry_amd.load_library().awry_host_threads(),
+                "note": "awry_count_batch: ASCII + offsets in host memory -> counts in host memory, PCIe-inclusive, through the Python mirror, "
+                        "median of 7 after 1 warm-up; the host packs 2 bits per letter on its worker pool (8 B per 31-mer over PCIe), "
+                        "counts return as 32-bit words; queries_per_s reuses the caller's result array, fresh_result_array allocates "
+                        "one per call (first-touch page faults + the allocator's mmap/munmap)"}
         result["variants"] = extra
 
         if args.cpu_seconds > 0:

@@ -115,7 +115,9 @@ int awry_count_batch(awry_index_t *idx, const uint8_t *qbytes, const uint64_t *q
 int awry_count_packed_kmers(awry_index_t *idx, const uint64_t *words, uint64_t n, int L, uint64_t *counts_out);
 /* FmIndex::parallel_locate, src/fm_index.rs:479-487.  CSR output, library-allocated (awry_free_buffer):
  * hits of query i are [hit_off[i], hit_off[i+1]) in ascending BWT-row order (src/fm_index.rs:521);
- * global_pos (nullable) receives (SA sample + steps) % bwt_len (src/fm_index.rs:534). */
+ * global_pos (nullable) receives (SA sample + steps) % bwt_len (src/fm_index.rs:534).  hits_out is nullable too: a
+ * caller that wants text positions only (8 B per hit over PCIe instead of 24) passes NULL and (record, offset) pairs
+ * are neither computed nor moved; with both NULL the call returns the offsets alone. */
 int awry_locate_batch(awry_index_t *idx, const uint8_t *qbytes, const uint64_t *qoff, uint64_t n,
                       uint64_t **hit_off_out, awry_pos_t **hits_out, uint64_t **global_pos_out);
 void awry_free_buffer(void *p);
@@ -156,6 +158,16 @@ int awry_read_query_file(const char *path, uint8_t **qbytes_out, uint64_t **qoff
 /* suffix array of a byte text ending in '$' (host SA-IS; stands in for libsufr, src/fm_index.rs:156-181) */
 int awry_host_suffix_array(const uint8_t *text, uint64_t n, uint64_t *sa_out);
 uint8_t awry_symbol_index(int alphabet, uint8_t ascii); /* Symbol::new_ascii(..).index(), src/alphabet.rs:109,152 */
+/* the host half of awry_count_batch / awry_locate_batch for nucleotide batches (caller side of src/fm_index.rs:455-487):
+ * n ASCII queries -> 2-bit words on the library's worker pool (AVX2), so that 8 B per 31-mer cross PCIe instead of 31.
+ * qoff == NULL: n queries of L bytes back to back; else query i = qbytes[qoff[i] .. qoff[i+1]) with 1..L letters and
+ * lens_out[i] receives its length.  W = ceil(L / 32) words per query (letter j in word j / 32, bits 2 (j % 32), A0 C1
+ * G2 T3, unused bits zero).  Queries holding a byte outside ACGTacgt are listed (ascending) in bad_out[0 .. *nbad_out)
+ * (room for n; nullable) -- the batch paths hand those to the generic kernel.  Needs no GPU; searches nothing. */
+int awry_host_pack_nt2(const uint8_t *qbytes, const uint64_t *qoff, uint64_t n, uint64_t L, uint64_t *words_out,
+                       uint32_t *lens_out, uint32_t *bad_out, uint64_t *nbad_out);
+int awry_host_threads(void); /* size of that pool: the CPUs this process may use (cgroup quota / affinity; AWRY_HOST_THREADS) */
+void awry_host_memcpy(void *dst, const void *src, uint64_t bytes); /* memcpy cut over that pool (what copies results out) */
 
 /* ---- device-resident API: pointers are device memory on replica `slot`'s GPU, work is queued on
  *      `stream` (a hipStream_t, NULL = default stream) and NOT synchronised --------------------------------- */

@@ -1019,3 +1019,46 @@ def test_amino_kmer_schedule_on_a_large_batch(oracle):
     side.synchronize()
     assert np.array_equal(d_c.cpu().numpy().astype(np.uint64), want)
     assert np.array_equal(ix.parallel_count_csr(qb, qo), want)
+
+
+@pytest.mark.gpu
+def test_host_packed_boundary_details(oracle):
+    """the host-packed lanes of parallel_count / parallel_locate (AVX2 packer on the worker pool, pinned staging, counts as
+    32-bit words over PCIe): a batch of several chunks in which a third of the queries hold other letters (N, IUPAC codes,
+    U, lower case) and travel as compact batches for the generic kernel; the first undefined query is named by its index;
+    hits_out = NULL returns the same offsets and text positions without (record, offset) pairs"""
+    text, st, hd = synth.make_text(500000, 0, 91, 4, 0.03)
+    ix = gpu_index(text, 0, 8, 0, st, hd)
+    oi = oracle.OracleIndex.from_text(text, 0, 8, 0, st, hd)
+    rng = np.random.default_rng(5)
+    for L in (31, 75):
+        nq = 2_600_000 if L == 31 else 1_300_000
+        q2d = synth.sampled_queries(text, nq, L, 100 + L, skip_amb=False)
+        q2d[q2d == ord("$")] = ord("A")
+        rnd = rng.random(nq) < 0.3
+        q2d[rnd] = synth.random_queries(int(rnd.sum()), L, 0, 7)
+        other = np.nonzero(rng.random(nq) < 0.33)[0]
+        q2d[other, rng.integers(0, L, len(other))] = rng.choice(np.frombuffer(b"NnRYKMSWUu", np.uint8), len(other))
+        low = np.nonzero(rng.random(nq) < 0.05)[0]
+        q2d[low] |= 0x20
+        qb, qo = synth.fixed_to_csr(q2d)
+        out = np.full(nq, 12345, dtype=np.uint64)
+        counts = ix.parallel_count_csr(qb, qo, out)
+        assert counts is out
+        sample = np.sort(rng.choice(nq, size=40000, replace=False))
+        sb, so = synth.fixed_to_csr(q2d[sample])
+        ooff, ogpos, opos, _ = oi.parallel_locate(sb, so, 4)
+        assert np.array_equal(np.diff(ooff), counts[sample])
+        off, g, p = ix.parallel_locate_csr(qb, qo)
+        assert np.array_equal(np.diff(off), counts) and len(g) == len(p) == int(off[-1])
+        assert np.array_equal(np.concatenate([g[int(off[i]):int(off[i + 1])] for i in sample]), ogpos)
+        assert np.array_equal(np.concatenate([p[int(off[i]):int(off[i + 1])] for i in sample]), opos)
+        off2, g2, p2 = ix.parallel_locate_csr(qb, qo, want_pos=False)
+        assert np.array_equal(off2, off) and np.array_equal(g2, g) and p2.shape == (0, 2)
+        bad = q2d.copy()
+        bad[nq - 7, L // 2] = ord("$")
+        bad[nq - 3, 0] = ord("#")
+        for fn in (ix.parallel_count_csr, ix.parallel_locate_csr):
+            with pytest.raises(AwryError) as e:
+                fn(*synth.fixed_to_csr(bad))
+            assert e.value.code == ERR_INVALID_QUERY and "query %d:" % (nq - 7) in str(e.value)

@@ -244,3 +244,58 @@ def test_c_abi_header_is_plain_c(tmp_path):
                            "-L", libdir, "-lawry_hip", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
     r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=60)
     assert r.returncode == 0, (r.stdout, r.stderr)
+
+
+def _ref_pack_nt2(q2d):
+    """numpy restatement of the packed-query layout: letter j in word j // 32, bits 2 (j % 32), A0 C1 G2 T3"""
+    n, L = q2d.shape
+    c = q2d & 0xDF
+    code = np.full(q2d.shape, 255, np.uint8)
+    for ch, v in ((65, 0), (67, 1), (71, 2), (84, 3)):
+        code[c == ch] = v
+    bad = np.nonzero((code == 255).any(1))[0]
+    code[code == 255] = 0
+    w = np.zeros((n, (L + 31) // 32), np.uint64)
+    for j in range(L):
+        w[:, j // 32] |= code[:, j].astype(np.uint64) << np.uint64(2 * (j % 32))
+    return w, bad
+
+
+@pytest.mark.parametrize("L", [1, 7, 31, 32, 33, 64, 101, 150])
+def test_host_packer_matches_layout_and_lists_other_letters(L):
+    """the host half of awry_count_batch (AVX2 packer on the worker pool): words equal the packed layout the kernels
+    read, lower case folds, and exactly the queries with a byte outside ACGTacgt are listed -- uniform and ragged"""
+    lib = awry_amd.load_library()
+    assert lib.awry_host_threads() >= 1
+    u64p, u32p = C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)
+    rng = np.random.default_rng(L)
+    n = 20011
+    q = rng.choice(np.frombuffer(b"ACGTacgt", np.uint8), size=(n, L))
+    bi = rng.integers(0, n, 50)
+    q[bi, rng.integers(0, L, 50)] = rng.choice(np.frombuffer(b"NnU$\xc1RY@`#", np.uint8), 50)
+    W = (L + 31) // 32
+    words, bad, nb = np.zeros((n, W), np.uint64), np.zeros(n, np.uint32), C.c_uint64()
+    flat = np.ascontiguousarray(q.reshape(-1))
+    assert lib.awry_host_pack_nt2(flat.ctypes.data, None, n, L, words.ctypes.data_as(u64p), None, bad.ctypes.data_as(u32p), C.byref(nb)) == 0
+    w, b = _ref_pack_nt2(q)
+    good = np.ones(n, bool)
+    good[b] = False
+    assert np.array_equal(bad[:nb.value], b.astype(np.uint32))
+    assert np.array_equal(words[good], w[good])
+    # ragged: per-query lengths 1..L at a stride of W words
+    lens = rng.integers(1, L + 1, n)
+    off = np.zeros(n + 1, np.uint64)
+    off[1:] = np.cumsum(lens)
+    rb = np.concatenate([q[i, :lens[i]] for i in range(n)])
+    words2, lo = np.zeros((n, W), np.uint64), np.zeros(n, np.uint32)
+    assert lib.awry_host_pack_nt2(rb.ctypes.data, off.ctypes.data_as(u64p), n, L, words2.ctypes.data_as(u64p), lo.ctypes.data_as(u32p),
+                                  bad.ctypes.data_as(u32p), C.byref(nb)) == 0
+    assert np.array_equal(lo, lens.astype(np.uint32))
+    listed = set(bad[:nb.value].tolist())
+    for i in range(0, n, 37):
+        ww, bb = _ref_pack_nt2(q[i:i + 1, :lens[i]])
+        assert (i in listed) == (len(bb) == 1)
+        if not len(bb):
+            exp = np.zeros(W, np.uint64)
+            exp[:ww.shape[1]] = ww[0]
+            assert np.array_equal(words2[i], exp), (L, i)

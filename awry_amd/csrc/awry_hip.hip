@@ -182,14 +182,12 @@ struct Replica {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   DevBuf<uint64_t> blocks, sa_words, seq_starts;
   DevBuf<SeedEntry> seed;
-  DevBuf<unsigned long long> chunk_counters;  // ring of work-queue heads, one per in-flight count / locate launch
   DevBuf<uint32_t> text4;                     // 4-bit text for seed-and-verify (device-only accelerator)
   DevBuf<uint8_t> text8;                      // the text as symbol indices, for the generic kernel's verify (any alphabet)
   DevBuf<uint32_t> dense_sa;                  // SA[j * dense_ratio] as u32 (device-only accelerator for locate)
   DevBuf<uint32_t> sa_nblock;                 // SA of the rows whose suffix starts with N (kept while locate has to walk)
   uint32_t dense_ratio = 0;                   // 0 = use the file's bit-packed samples
   bool verify_kmers = false;                  // also use seed-and-verify in the k-mer (L <= 32) kernel
-  std::atomic<unsigned> launch_seq{0};
   // survivor lists of the two-phase count schedule, one per stream (launches on one stream are ordered, so reuse is safe)
   struct SurvScratch {
     DevBuf<uint64_t> w, range;
@@ -200,6 +198,10 @@ struct Replica {
     DevBuf<uint64_t> u_words;
     DevBuf<uint32_t> u_list;
     DevBuf<unsigned long long> u_bad;
+    // work-queue heads of the chunk / locate kernels launched on this stream: launches on one stream are ordered, so a
+    // head is free again by the time the ring comes back to it, however many launches other streams have in flight
+    DevBuf<unsigned long long> counters;
+    unsigned counter_seq = 0;
   };
   std::mutex scratch_mu;
   std::map<hipStream_t, std::unique_ptr<SurvScratch>> scratch;
@@ -213,7 +215,8 @@ struct Replica {
       for (auto& ls : lane_stream) if (ls) (void)hipStreamDestroy(ls);
       if (ev0) (void)hipEventDestroy(ev0);
       if (ev1) (void)hipEventDestroy(ev1);
-      blocks.reset(); sa_words.reset(); seq_starts.reset(); seed.reset(); chunk_counters.reset(); dense_sa.reset(); text4.reset();
+      blocks.reset(); sa_words.reset(); seq_starts.reset(); seed.reset(); dense_sa.reset(); text4.reset();
+      scratch.clear();
       sa_nblock.reset(); text8.reset();
     }
   }
@@ -278,6 +281,20 @@ int count_kernel_mode(uint64_t bwt_len, int seed_k, bool seeded) {
 
 bool narrow(const HostIndex& h) { return h.bwt_len < (1ull << 32) - 512; }
 
+// HBM the accelerator policies may plan with on the current device: what is free now, capped by AWRY_HBM_BUDGET_GB (a
+// process that shares the GPU, or wants room for its own buffers, sets it; the seed table is sized to 70 % and the
+// verify accelerators admitted below 50 % of this figure)
+bool hbm_budget(size_t* free_out) {
+  size_t free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return false;
+  if (const char* e = getenv("AWRY_HBM_BUDGET_GB")) {
+    const double gb = atof(e);
+    if (gb > 0) free_b = std::min<size_t>(free_b, (size_t)(gb * 1e9));
+  }
+  *free_out = free_b;
+  return true;
+}
+
 int default_seed_k(const HostIndex& h) {
   if (!narrow(h)) return 0;
   const bool nt = h.alphabet == NUCLEOTIDE;
@@ -285,8 +302,8 @@ int default_seed_k(const HostIndex& h) {
   if (!nt) {  // amino: 20^k ~ 1..20 x bwt_len (Swiss-Prot 9e7 -> k = 7, 10 GB), same memory rule as below
     int k = (int)std::floor(std::log((double)h.bwt_len) / std::log(20.0)) + 1;
     k = std::max(1, std::min(k, 7));
-    size_t free_b = 0, total_b = 0;
-    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
+    size_t free_b = 0;
+    if (hbm_budget(&free_b))
       while (k > 1 && 8.5 * std::pow(20.0, k) > 0.7 * (double)free_b) k--;
     return k;
   }
@@ -296,8 +313,8 @@ int default_seed_k(const HostIndex& h) {
   // table and its build scratch (1/4 of it) must fit in 70 % of the free HBM, else k drops.
   int k = (int)std::floor(std::log((double)h.bwt_len) / std::log(4.0)) + 2;
   k = std::max(1, std::min(k, 17));
-  size_t free_b = 0, total_b = 0;
-  if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
+  size_t free_b = 0;
+  if (hbm_budget(&free_b))
     while (k > 1 && (double)(10ull << (2 * k)) > 0.7 * (double)free_b) k--;  // 8 B + 2 B scratch per entry
   return k;
 }
@@ -392,7 +409,6 @@ std::unique_ptr<Replica> make_replica(awry_index* ix, int device) {
   r->blocks.alloc(h.blocks.size());
   r->sa_words.alloc(h.sa_words.size() + 1);  // +1: the straddle read of the last sample never leaves the buffer
   r->seq_starts.alloc(std::max<size_t>(1, h.seq_starts.size()));
-  r->chunk_counters.alloc(64);
   HIP_CHECK(hipMemcpy(r->blocks.p, h.blocks.data(), h.blocks.size() * 8, hipMemcpyHostToDevice));
   HIP_CHECK(hipMemset(r->sa_words.p, 0, (h.sa_words.size() + 1) * 8));
   if (!h.sa_words.empty()) HIP_CHECK(hipMemcpy(r->sa_words.p, h.sa_words.data(), h.sa_words.size() * 8, hipMemcpyHostToDevice));
@@ -426,8 +442,8 @@ std::unique_ptr<Replica> make_replica(awry_index* ix, int device) {
   if (vreq == -2) {  // policy: keep the accelerators (dense SA 4 B + text 1.5 B / 1 B per symbol) resident when they fit comfortably
     vreq = -1;
     const char* e = getenv("AWRY_VERIFY");
-    size_t free_b = 0, total_b = 0;
-    if (!(e && !strcmp(e, "0")) && narrow(h) && hipMemGetInfo(&free_b, &total_b) == hipSuccess && (double)h.bwt_len * 7.0 < 0.5 * (double)free_b)
+    size_t free_b = 0;
+    if (!(e && !strcmp(e, "0")) && narrow(h) && hbm_budget(&free_b) && (double)h.bwt_len * 7.0 < 0.5 * (double)free_b)
       vreq = e && atoi(e) > 0 ? atoi(e) : 2;
   }
   if (vreq >= 0) build_verify(ix, *r, vreq);
@@ -475,8 +491,16 @@ void launch_scan(Replica& r, const uint64_t* d_counts, uint64_t n, uint64_t* d_h
   HIP_CHECK(hipGetLastError());
 }
 
+Replica::SurvScratch* surv_scratch(Replica& r, hipStream_t s);
+
 unsigned long long* next_counter(Replica& r, hipStream_t s) {
-  unsigned long long* ctr = r.chunk_counters.p + (r.launch_seq.fetch_add(1) % 64u);
+  Replica::SurvScratch* sc = surv_scratch(r, s);
+  unsigned long long* ctr;
+  {
+    std::lock_guard<std::mutex> lock(r.scratch_mu);
+    if (!sc->counters.p) sc->counters.alloc(8);
+    ctr = sc->counters.p + (sc->counter_seq++ & 7u);
+  }
   HIP_CHECK(hipMemsetAsync(ctr, 0, 8, s));
   return ctr;
 }
@@ -1670,6 +1694,10 @@ void fill_ref_kmer_table(awry_index* ix) {
   HostIndex& h = ix->host;
   const uint64_t nslots = ref_kmer_table_entries(h.alphabet, h.kmer_len);
   if (h.ref_kmer_table.size() == 2 * nslots) return;
+  if (ix->reps.empty()) {  // saving is host work: no replica, no GPU needed
+    fill_ref_kmer_table_host(h);
+    return;
+  }
   Replica& r = replica(ix, 0);
   DevBuf<uint64_t> tab(2 * nslots);
   const dim3 g(grid_for(r, nslots, 256)), b(256);
@@ -1714,10 +1742,44 @@ const char* awry_last_error(void) { return g_last_error.c_str(); }
 
 // build_device: >= 0 construct on that GPU (sa_builder.hip); AWRY_BUILD_HOST (-1) host SA-IS;
 // AWRY_BUILD_AUTO (-2): GPU 0 when one is visible and the text is large enough to pay for it
+// The index is built over the CANONICAL text: every byte replaced by the letter of its symbol index (lower case folded,
+// U -> T, IUPAC codes and anything else -> N; non-standard residues -> X) -- the map queries go through
+// (src/alphabet.rs:109-114,169-248).  Suffixes must be sorted in the order the BWT encodes them: sorted by raw bytes, a
+// text with R / Y / K ... (or B / Z / U / O / J in proteins) would put its N- (X-) suffixes in several places while
+// prefix_sums assume one block, and LF steps and text comparison would disagree.  Returns true and fills `out` when the
+// text had to be rewritten.  An inner '$' / '#' is an argument error (the text model has exactly one sentinel, at the end).
+static bool canonical_text(const uint8_t* text, uint64_t bwt_len, int alphabet, std::vector<uint8_t>& out) {
+  uint8_t canon[256];
+  for (int b = 0; b < 256; b++) canon[b] = ascii_of_index(alphabet, index_of_ascii(alphabet, (uint8_t)b));
+  const uint64_t body = bwt_len - 1;
+  std::atomic<int> other{0}, sentinel{0};
+  HostPool::instance().run_ranges(body, 1u << 22, [&](uint64_t lo, uint64_t hi) {
+    unsigned diff = 0, sent = 0;
+    for (uint64_t i = lo; i < hi; i++) {  // branch-free: vectorises
+      const uint8_t c = canon[text[i]];
+      diff |= (unsigned)(c != text[i]);
+      sent |= (unsigned)(c == '$');
+    }
+    if (diff) other.store(1, std::memory_order_relaxed);
+    if (sent) sentinel.store(1, std::memory_order_relaxed);
+  });
+  if (sentinel.load()) throw ArgError("the text holds '$' or '#' before its last byte (the text model has one sentinel, at the end)");
+  if (!other.load()) return false;
+  out.resize(bwt_len);
+  HostPool::instance().run_ranges(body, 1u << 22, [&](uint64_t lo, uint64_t hi) {
+    for (uint64_t i = lo; i < hi; i++) out[i] = canon[text[i]];
+  });
+  out[body] = '$';
+  return true;
+}
+
 static void construct(awry_index* ix, const uint8_t* text, uint64_t bwt_len, int alphabet, uint64_t sa_ratio, uint8_t kmer_len,
                       const uint64_t* seq_starts, const char* const* headers, uint64_t nseq, int build_device) {
   static const uint64_t zero = 0;
   if (nseq == 0 || !seq_starts) { seq_starts = &zero; nseq = 1; headers = nullptr; }
+  if (bwt_len == 0 || text[bwt_len - 1] != '$') throw ArgError("text must end with '$'");
+  std::vector<uint8_t> canon;
+  if (canonical_text(text, bwt_len, alphabet, canon)) text = canon.data();
   if (build_device == AWRY_BUILD_AUTO) {
     const char* e = getenv("AWRY_BUILD");
     int ndev = 0;
@@ -1796,6 +1858,9 @@ int awry_set_devices(awry_index_t* idx, const int* device_ids, int n_devices) {
   return guarded([&] {
     require(idx != nullptr, "null index");
     if (n_devices <= 0 || !device_ids) throw NoDeviceError("awry_set_devices needs at least one GPU: there is no CPU search path");
+    // the old replicas go first: the policies below size the seed table and the accelerators from the HBM that is free,
+    // and a rebuilt replica on the same GPU must not see half of it (if the build fails the index is left without replicas)
+    idx->reps.clear();
     std::vector<std::unique_ptr<Replica>> reps(n_devices);
     if (n_devices == 1) {
       reps[0] = make_replica(idx, device_ids[0]);

@@ -487,6 +487,77 @@ void block_from_reference(HostIndex& ix, uint64_t b, const uint64_t* in) {
   set_milestones(blk, A, in + 4 * P);
 }
 
+// ------------------------------------------------------------------ the reference's k-mer table, on the host
+
+namespace {
+// Occ(idx, row) inclusive of row on the host copy (device layout): src/bwt.rs:338-357.  Used only to write the k-mer
+// table of an .awry file when no GPU replica exists -- never to answer a query.
+uint64_t host_rank(const HostIndex& ix, uint64_t row, int idx) {
+  const int A = ix.alphabet, BW = block_words(A), P = num_planes(A);
+  const uint64_t b = row >> 8;
+  const int p = (int)(row & 255);
+  const uint64_t* blk = ix.blocks.data() + b * BW;
+  const uint32_t code = code_of_index(A, idx);
+  uint64_t cnt = 0;
+  for (int l = 0; l < 4; l++) {
+    const int t = p - 64 * l;
+    if (t < 0) break;
+    uint64_t pred = ~0ull;
+    for (int pl = 0; pl < P; pl++) pred &= blk[plane_word(A, pl, l)] ^ (((code >> pl) & 1u) ? 0ull : ~0ull);
+    cnt += (uint64_t)__builtin_popcountll(pred & (t >= 63 ? ~0ull : ((1ull << (t + 1)) - 1)));
+  }
+  uint64_t ms;
+  if (A == NUCLEOTIDE) {
+    const int letter = nt_letter_of_index(idx);
+    if (letter >= 0) ms = blk[nt_ms_word(letter)];
+    else {  // N: derived (layout.h)
+      uint64_t sum = 0;
+      for (int l = 0; l < 4; l++) sum += blk[nt_ms_word(l)];
+      ms = 256 * b - sum - (ix.sentinel_row < 256 * b ? 1 : 0);
+    }
+  } else {
+    const int t = idx - 1;
+    ms = (blk[aa_ms_word(t)] >> (32 * aa_ms_half(t))) & 0xffffffffull;
+  }
+  return ms + cnt;
+}
+}  // namespace
+
+// src/kmer_lookup_table.rs:121-167, as ref_kmer_table_kernel computes it on a GPU: slot = sum_j s_j sigma^j with s_0 the
+// LAST symbol, digits 1..sigma-1 only, k-1 steps without an emptiness check, every other slot {1, 0}
+void fill_ref_kmer_table_host(HostIndex& ix) {
+  const uint64_t nslots = ref_kmer_table_entries(ix.alphabet, ix.kmer_len);
+  if (ix.ref_kmer_table.size() == 2 * nslots) return;
+  const uint64_t sigma = (uint64_t)cardinality(ix.alphabet) - 2;
+  const int k = ix.kmer_len;
+  std::vector<uint64_t> tab(2 * nslots);
+  parallel_ranges(nslots, 1, worker_count(nslots, 1u << 14), [&](unsigned, uint64_t lo, uint64_t hi) {
+    for (uint64_t slot = lo; slot < hi; slot++) {
+      uint64_t sp = 1, ep = 0, rem = slot;
+      bool populated = k > 0;
+      for (int j = 0; j < k; j++) { if (rem % sigma == 0) populated = false; rem /= sigma; }
+      if (populated) {
+        rem = slot;
+        int idx = (int)(rem % sigma);
+        rem /= sigma;
+        sp = ix.prefix_sums[idx];
+        ep = ix.prefix_sums[idx + 1] - 1;
+        for (int j = 1; j < k; j++) {  // update_range_with_symbol, src/fm_index.rs:559-582
+          idx = (int)(rem % sigma);
+          rem /= sigma;
+          const uint64_t c = ix.prefix_sums[idx];
+          const uint64_t s2 = c + host_rank(ix, sp - 1, idx);
+          ep = c + host_rank(ix, ep, idx) - 1;
+          sp = s2;
+        }
+      }
+      tab[2 * slot] = sp;
+      tab[2 * slot + 1] = ep;
+    }
+  });
+  ix.ref_kmer_table = std::move(tab);
+}
+
 // ------------------------------------------------------------------ .awry v1
 
 static const char MAGIC[12] = "AWRY-Index\n";  // 11 bytes on disk, src/fm_index_file.rs:18

@@ -65,6 +65,10 @@ void gpu_build_index(HostIndex& ix, const uint8_t* text, uint64_t bwt_len, int d
 void block_to_reference(const HostIndex& ix, uint64_t b, uint64_t* out /* 20 or 44 words */);
 void block_from_reference(HostIndex& ix, uint64_t b, const uint64_t* in);
 
+// the reference's k-mer table content (src/kmer_lookup_table.rs:121-167) computed on the host copy: what awry_save
+// writes when the index has no GPU replica (with one, ref_kmer_table_kernel fills it)
+void fill_ref_kmer_table_host(HostIndex& ix);
+
 // .awry v1 (src/fm_index_file.rs:42-106,132-287); save needs ix.ref_kmer_table filled
 void save_awry(const HostIndex& ix, const std::string& path);
 void load_awry(HostIndex& ix, const std::string& path);

@@ -212,10 +212,10 @@ inline bool pack_query(const uint8_t* p, uint64_t len, const uint8_t* end, uint6
       alignas(32) uint8_t tmp[32];
       memset(tmp, 'A', 32);
       memcpy(tmp, p + j, (size_t)m);
-      out[k] = pack32(tmp, m, &ok);
+      _mm_stream_si64(reinterpret_cast<long long*>(out + k), (long long)pack32(tmp, m, &ok));
     }
   }
-  for (; k < W; k++) out[k] = 0;
+  for (; k < W; k++) _mm_stream_si64(reinterpret_cast<long long*>(out + k), 0);  // (every word of a line by the same kind of store)
   return ok;
 }
 

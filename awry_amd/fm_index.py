@@ -151,6 +151,8 @@ class FmIndex:
         L = _lib.load_library()
         t = np.frombuffer(_as_bytes(text), dtype=np.uint8) if not isinstance(text, np.ndarray) else np.ascontiguousarray(text, np.uint8)
         st = np.ascontiguousarray(list(seq_starts), dtype=np.uint64)
+        if len(st) != len(headers):
+            raise ValueError("seq_starts and headers must have one entry per record (%d != %d)" % (len(st), len(headers)))
         hd = (C.c_char_p * len(headers))(*[h.encode() for h in headers])
         h = C.c_void_p()
         _check(L.awry_build_from_text_on(t.ctypes.data, len(t), alphabet, sa_ratio, kmer_len, st.ctypes.data_as(_u64p), hd,

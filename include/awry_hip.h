@@ -68,12 +68,15 @@ int awry_build_from_text_on(const uint8_t *text, uint64_t bwt_len, int alphabet,
                             awry_index_t **out);
 /* FmIndex::load / FmIndex::save, src/fm_index_file.rs:132,42 (.awry v1, byte-compatible) */
 int awry_load(const char *path, awry_index_t **out);
-int awry_save(awry_index_t *idx, const char *path); /* needs a device: fills the k-mer table on the GPU */
+int awry_save(awry_index_t *idx, const char *path); /* needs no device (the k-mer table is filled on a replica's GPU when there is one, else on the host) */
 void awry_free(awry_index_t *idx);
 
 /* ---- device placement (replaces rayon's global pool, src/fm_index.rs:455-487) ---------------------- */
 /* replicate the index into the HBM of each listed device and build its seed table; batches are then
- * sharded contiguously over the replicas.  n_devices == 0 is an error: there is no CPU backend. */
+ * sharded contiguously over the replicas.  n_devices == 0 is an error: there is no CPU backend.  Replaces (and first
+ * releases) any earlier replicas.  HBM use: the default policies size the seed table to 70 % of the free HBM and keep
+ * the locate / verify accelerators (7 B per text symbol) when they fit in half of it -- ~160 GB for a GRCh38-scale
+ * index; AWRY_HBM_BUDGET_GB caps the figure they plan with, AWRY_SEED_K / AWRY_VERIFY=0 pin the choices. */
 int awry_set_devices(awry_index_t *idx, const int *device_ids, int n_devices);
 /* device-side seed-table length (performance knob only; results do not depend on it).  0 disables,
  * -1 picks the default.  Takes effect immediately on all replicas. */
@@ -170,7 +173,10 @@ int awry_host_threads(void); /* size of that pool: the CPUs this process may use
 void awry_host_memcpy(void *dst, const void *src, uint64_t bytes); /* memcpy cut over that pool (what copies results out) */
 
 /* ---- device-resident API: pointers are device memory on replica `slot`'s GPU, work is queued on
- *      `stream` (a hipStream_t, NULL = default stream) and NOT synchronised --------------------------------- */
+ *      `stream` (a hipStream_t, NULL = default stream) and NOT synchronised.  Scratch (survivor lists, work-queue
+ *      heads) is kept per stream, so any number of launches may be in flight across streams.  Query byte buffers
+ *      (d_qbytes, d_ascii) are read in aligned 8-byte words: they must be readable up to 8 bytes past the last
+ *      query (allocations of awry_dev_malloc and hipMalloc are) ------------------------------------------------ */
 int awry_replica_device(const awry_index_t *idx, int slot);
 /* fixed-length ACGT reads, ASCII n*L bytes -> n * ceil(L/32) packed u64 words (letter j in word j/32, bits 2(j%32));
  * *d_bad (u64 on device, caller-zeroed) counts queries with other bytes */

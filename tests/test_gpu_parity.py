@@ -13,6 +13,16 @@ from awry_amd.fm_index import ERR_INVALID_QUERY, AwryError, FmIndex, SearchRange
 from tests import synth
 
 pytestmark = pytest.mark.gpu
+
+
+def awry_build_host():
+    from awry_amd.fm_index import BUILD_HOST
+    return BUILD_HOST
+
+
+def awry_pack(queries):
+    from awry_amd.fm_index import pack_queries
+    return pack_queries(queries)
 GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.json")))
 
 
@@ -1062,3 +1072,43 @@ def test_host_packed_boundary_details(oracle):
             with pytest.raises(AwryError) as e:
                 fn(*synth.fixed_to_csr(bad))
             assert e.value.code == ERR_INVALID_QUERY and "query %d:" % (nq - 7) in str(e.value)
+
+
+@pytest.mark.parametrize("alphabet", [0, 1])
+def test_non_canonical_text_letters(oracle, alphabet):
+    """a text with IUPAC codes / non-standard residues, U and lower case is indexed as its canonical form, so counts and
+    locations equal brute force over the symbol indices of text and query -- with the seed-and-verify accelerators and
+    without them, on the host-built and on the GPU-built index (round 1 sorted suffixes by raw bytes: LF steps and text
+    comparison then disagreed)"""
+    rng = np.random.default_rng(40 + alphabet)
+    letters = b"ACGT" * 6 + b"acgtRYKMSWNnUu" if alphabet == 0 else b"ACDEFGHIKLMNPQRSTVWY" * 3 + b"acdxXBJOUZbz"
+    n = 4000
+    body = rng.choice(np.frombuffer(letters, np.uint8), size=n)
+    body[1000:1040] = ord("N") if alphabet == 0 else ord("X")
+    text = np.concatenate([body, np.frombuffer(b"$", np.uint8)])
+    O = oracle.lib()
+    qs = []
+    for L in (3, 6, 11, 17, 30):
+        st = rng.integers(0, n - L, size=120)
+        for s in st:
+            qs.append(bytes(body[s:s + L]))
+            qs.append(bytes(body[s:s + L]).upper())
+        qs += [bytes(x) for x in synth.random_queries(40, L, alphabet, L)]
+    u64p = C.POINTER(C.c_uint64)
+    want_count, want_pos = [], []
+    for q in qs:
+        buf = np.zeros(n + 1, np.uint64)
+        c = O.orc_brute_locate(alphabet, text.ctypes.data, len(text), q, len(q), buf.ctypes.data_as(u64p), len(buf))
+        want_count.append(c)
+        want_pos.append(np.sort(buf[:c]))
+    for dev in (awry_amd_build_host(), 0):
+        ix = FmIndex.from_text(text, alphabet, 4, 0, build_device=dev).set_devices([0])
+        for verify in (2, -1):
+            ix.set_verify(verify)
+            counts = ix.parallel_count(qs)
+            assert np.array_equal(counts, np.array(want_count, np.uint64)), (dev, verify)
+            off, g, p = ix.parallel_locate_csr(*awry_pack(qs))
+            for i in range(len(qs)):
+                assert np.array_equal(np.sort(g[int(off[i]):int(off[i + 1])]), want_pos[i]), (dev, verify, qs[i])
+            for q, c in list(zip(qs, want_count))[::37]:
+                assert ix.count_string(q) == c

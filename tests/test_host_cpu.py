@@ -299,3 +299,44 @@ def test_host_packer_matches_layout_and_lists_other_letters(L):
             exp = np.zeros(W, np.uint64)
             exp[:ww.shape[1]] = ww[0]
             assert np.array_equal(words2[i], exp), (L, i)
+
+
+@pytest.mark.parametrize("alphabet", [0, 1])
+def test_text_is_canonicalised_before_suffix_sorting(alphabet):
+    """a text with lower case, IUPAC codes / non-standard residues and U is indexed as its canonical form (the map queries go
+    through): same index as the canonical text gives, bit for bit; an inner '$' / '#' is an argument error"""
+    rng = np.random.default_rng(alphabet)
+    letters = b"ACGTacgtRYKMSWNnUu" if alphabet == 0 else b"ACDEFGHIKLMNPQRSTVWYacdxXBJOUZbz*"
+    body = rng.choice(np.frombuffer(letters, np.uint8), size=5000)
+    text = np.concatenate([body, np.frombuffer(b"$", np.uint8)])
+    lib = awry_amd.load_library()
+    canon = np.array([ord("$")] * 256, np.uint8)
+    names = b"$ACGNT" if alphabet == 0 else b"$ACDEFGHIKLMNPQRSTVWXY"
+    for b in range(256):
+        canon[b] = names[lib.awry_symbol_index(alphabet, b)]
+    ctext = canon[text]
+    assert (ctext != text).any() and ctext[-1] == ord("$")
+    a = FmIndex.from_text(text, alphabet, 4, 0, build_device=awry_amd.fm_index.BUILD_HOST)
+    b = FmIndex.from_text(ctext, alphabet, 4, 0, build_device=awry_amd.fm_index.BUILD_HOST)
+    assert np.array_equal(a.device_block_words(), b.device_block_words())
+    assert np.array_equal(a.sa_words(), b.sa_words()) and np.array_equal(a.prefix_sums(), b.prefix_sums())
+    bad = text.copy()
+    bad[100] = ord("#")
+    with pytest.raises(AwryError) as e:
+        FmIndex.from_text(bad, alphabet, 4, 0, build_device=awry_amd.fm_index.BUILD_HOST)
+    assert e.value.code == ERR_ARG
+
+
+@pytest.mark.parametrize("alphabet,kmer_len", [(0, 0), (0, 4), (1, 0), (1, 3)])
+def test_save_without_a_device_is_byte_identical_to_reference_format(oracle, tmp_path, alphabet, kmer_len):
+    """FmIndex::save needs no GPU: with no replica the reference's (partially populated) k-mer table is computed on the
+    host copy (src/kmer_lookup_table.rs:121-167), and the file equals the oracle's writer byte for byte"""
+    text, st, hd = synth.make_text(9000, alphabet, 5 + alphabet, 3, 0.04)
+    ix = FmIndex.from_text(text, alphabet, 6, kmer_len, st, hd, build_device=awry_amd.fm_index.BUILD_HOST)
+    oi = oracle.OracleIndex.from_text(text, alphabet, 6, kmer_len, st, hd)
+    a, b = str(tmp_path / "a.awry"), str(tmp_path / "b.awry")
+    ix.save(a)
+    oi.save(b)
+    assert open(a, "rb").read() == open(b, "rb").read()
+    with pytest.raises(ValueError):
+        FmIndex.from_text(text, alphabet, 6, kmer_len, st, hd[:-1])

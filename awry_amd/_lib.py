@@ -112,10 +112,13 @@ def load_library():
     sig("awry_dev_count_nt2_tally", i32, vp, i32, vp, u64, i32, vp, i32, vp, vp)
     sig("awry_dev_count_ascii", i32, vp, i32, vp, vp, u64, vp, vp, vp, vp)
     sig("awry_dev_count_ascii_uniform", i32, vp, i32, vp, u64, u64, vp, vp, vp)
+    sig("awry_dev_count_ascii_uniform_tally", i32, vp, i32, vp, u64, u64, vp, vp, vp)
     sig("awry_dev_scan_scratch_bytes", u64, u64)
     sig("awry_dev_scan_counts", i32, vp, i32, vp, u64, vp, vp, vp)
     sig("awry_dev_locate", i32, vp, i32, vp, i32, vp, u64, u64, vp, vp, vp)
     sig("awry_dev_count_nt2_long", i32, vp, i32, vp, u64, i32, vp, vp, i32, vp)
+    sig("awry_dev_locate_tally", i32, vp, i32, vp, i32, vp, u64, u64, vp, vp, vp, vp)
+    sig("awry_dev_phase_marker", i32, vp, i32, i32, vp)
     sig("awry_set_locate_sa_ratio", i32, vp, i32)
     sig("awry_locate_sa_ratio", i32, vp)
     sig("awry_set_verify", i32, vp, i32)

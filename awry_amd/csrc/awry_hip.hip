@@ -396,6 +396,10 @@ std::unique_ptr<Replica> make_replica(awry_index* ix, int device) {
   if (e != hipSuccess || ndev == 0) throw NoDeviceError("no HIP device available (there is no CPU search path)");
   require(device >= 0 && device < ndev, "device id out of range");
   HIP_CHECK(hipSetDevice(device));
+  // replicas of one GPU are built one after the other (each sizes its seed table and accelerators from the HBM that is
+  // free when its turn comes); replicas of different GPUs build concurrently
+  static std::mutex build_mu[64];
+  std::lock_guard<std::mutex> build_lock(build_mu[device & 63]);
   auto r = std::make_unique<Replica>();
   r->device = device;
   hipDeviceProp_t prop;
@@ -507,7 +511,7 @@ unsigned long long* next_counter(Replica& r, hipStream_t s) {
 
 // d_range_start[q * rs_stride] = first BWT row of query q's range
 void launch_locate(Replica& r, const uint64_t* d_range_start, int rs_stride, const uint64_t* d_hit_off, uint64_t n, uint64_t total,
-                   uint64_t* d_gpos, uint64_t* d_pos, hipStream_t s) {
+                   uint64_t* d_gpos, uint64_t* d_pos, hipStream_t s, unsigned long long* d_tally = nullptr) {
   if (total == 0) return;
   static const bool scalar = getenv("AWRY_LOCATE_KERNEL") && !strcmp(getenv("AWRY_LOCATE_KERNEL"), "scalar");
   if (scalar && rs_stride == 2) {  // round-1 baseline kernel: one hit per lane, global binary search, file samples only
@@ -536,10 +540,12 @@ void launch_locate(Replica& r, const uint64_t* d_range_start, int rs_stride, con
   const dim3 gw(grid_for(r, total, 256, 7));
   static const bool generic_walk = getenv("AWRY_LOCATE_WALK") && !strcmp(getenv("AWRY_LOCATE_WALK"), "generic");
   static const bool direct_walk = getenv("AWRY_LOCATE_WALK") && !strcmp(getenv("AWRY_LOCATE_WALK"), "direct");
-  if (r.dev.alphabet == NUCLEOTIDE && !generic_walk && !direct_walk)
-    hipLaunchKernelGGL(locate_walk_nt_lane_kernel<true>, dim3(grid_for(r, total, 256, 4)), b, 0, s, r.dev, total, dense, r.dense_ratio, d_gpos, wctr);
+  if (r.dev.alphabet == NUCLEOTIDE && !generic_walk && !direct_walk && d_tally)
+    hipLaunchKernelGGL((locate_walk_nt_lane_kernel<true, true>), dim3(grid_for(r, total, 256, 4)), b, 0, s, r.dev, total, dense, r.dense_ratio, d_gpos, wctr, d_tally);
+  else if (r.dev.alphabet == NUCLEOTIDE && !generic_walk && !direct_walk)
+    hipLaunchKernelGGL((locate_walk_nt_lane_kernel<true, false>), dim3(grid_for(r, total, 256, 4)), b, 0, s, r.dev, total, dense, r.dense_ratio, d_gpos, wctr, nullptr);
   else if (r.dev.alphabet == NUCLEOTIDE && !generic_walk)
-    hipLaunchKernelGGL(locate_walk_nt_lane_kernel<false>, dim3(grid_for(r, total, 256, 8)), b, 0, s, r.dev, total, dense, r.dense_ratio, d_gpos, wctr);
+    hipLaunchKernelGGL((locate_walk_nt_lane_kernel<false, false>), dim3(grid_for(r, total, 256, 8)), b, 0, s, r.dev, total, dense, r.dense_ratio, d_gpos, wctr, nullptr);
   else if (r.dev.alphabet == NUCLEOTIDE) hipLaunchKernelGGL(locate_walk_kernel<NUCLEOTIDE>, gw, b, 0, s, r.dev, total, dense, r.dense_ratio, d_gpos, d_pos, wctr);
   else hipLaunchKernelGGL(locate_walk_kernel<AMINO>, gw, b, 0, s, r.dev, total, dense, r.dense_ratio, d_gpos, d_pos, wctr);
   if (d_pos) hipLaunchKernelGGL(localise_walked_kernel, dim3(grid_for(r, total, 256)), b, 0, s, r.dev, total, d_gpos, d_pos);
@@ -828,7 +834,7 @@ void check_status(const ChunkBuffers& cb, uint64_t first_query) {
 // generic kernel on what it listed).  Anything else: the generic kernel reading its queries at q * L.
 // d_ranges (optional): (start, end) / RS_* words per query for the locate pass, as launch_count_ascii writes them.
 void launch_count_ascii_uniform(Replica& r, const uint8_t* d_q, uint64_t n, uint64_t L, uint64_t* d_counts, uint8_t* d_status, hipStream_t s,
-                                uint64_t* d_ranges = nullptr) {
+                                uint64_t* d_ranges = nullptr, unsigned long long* d_tally = nullptr) {
   if (n == 0) return;
   require(L >= 1, "query length must be at least 1");
   static const bool off = getenv("AWRY_AA_KMER") && !strcmp(getenv("AWRY_AA_KMER"), "0");
@@ -857,6 +863,7 @@ void launch_count_ascii_uniform(Replica& r, const uint8_t* d_q, uint64_t n, uint
     return;
   }
   if (!two_phase) {
+    require(!d_tally, "the census is kept by the amino k-mer schedule only");
     launch_count_ascii(r, d_q, nullptr, n, d_counts, d_ranges, d_status, s, true, L);
     return;
   }
@@ -869,7 +876,7 @@ void launch_count_ascii_uniform(Replica& r, const uint8_t* d_q, uint64_t n, uint
     sc->cap = 0;  // the nucleotide k-mer path re-allocates its three lists together
   }
   if (!sc->count.p) sc->count.alloc(nblk);
-  const QueryList ql{sc->q.p, sc->count.p, per_block, nullptr, nullptr, 0};
+  const QueryList ql{sc->q.p, sc->count.p, per_block, nullptr, nullptr, 0, d_tally};
   // Two queries in flight per lane (one: the same rate; four: 141 VGPRs, 10 % slower).  The second pass is a latency
   // chain over a few per cent of the batch; running it for the first half of a batch on a side stream beside the first
   // pass of the second half (event fork / join) was measured and costs more than it hides (12.7 -> 10.7 G present
@@ -2304,6 +2311,17 @@ int awry_dev_count_ascii_uniform(awry_index_t* idx, int slot, const void* d_qbyt
   });
 }
 
+int awry_dev_count_ascii_uniform_tally(awry_index_t* idx, int slot, const void* d_qbytes, uint64_t n, uint64_t len, void* d_counts,
+                                       void* d_tally, void* stream) {
+  return guarded([&] {
+    Replica& r = replica(idx, slot);
+    require((d_qbytes && d_counts && d_tally) || n == 0, "null device pointer");
+    require(r.dev.alphabet == AMINO, "the census of the uniform entry point is kept by the amino k-mer schedule");
+    launch_count_ascii_uniform(r, (const uint8_t*)d_qbytes, n, len, (uint64_t*)d_counts, nullptr, (hipStream_t)stream, nullptr,
+                               (unsigned long long*)d_tally);
+  });
+}
+
 uint64_t awry_dev_scan_scratch_bytes(uint64_t n) { return (scan_tiles(n) + 1) * 8; }
 
 int awry_dev_scan_counts(awry_index_t* idx, int slot, const void* d_counts, uint64_t n, void* d_hit_off, void* d_scratch, void* stream) {
@@ -2322,6 +2340,27 @@ int awry_dev_locate(awry_index_t* idx, int slot, const void* d_ranges, int range
     require(range_stride == 1 || range_stride == 2, "range_stride must be 1 (starts) or 2 ((start,end) pairs)");
     launch_locate(r, (const uint64_t*)d_ranges, range_stride, (const uint64_t*)d_hit_off, n, total, (uint64_t*)d_global_pos,
                   (uint64_t*)d_pos, (hipStream_t)stream);
+  });
+}
+
+int awry_dev_locate_tally(awry_index_t* idx, int slot, const void* d_ranges, int range_stride, const void* d_hit_off, uint64_t n,
+                          uint64_t total, void* d_global_pos, void* d_pos, void* d_tally, void* stream) {
+  return guarded([&] {
+    Replica& r = replica(idx, slot);
+    require((d_ranges && d_hit_off && d_global_pos && d_tally) || total == 0, "null device pointer");
+    require(range_stride == 1 || range_stride == 2, "range_stride must be 1 (starts) or 2 ((start,end) pairs)");
+    require(r.dev.alphabet == NUCLEOTIDE, "the walk census is kept by the nucleotide walk kernel");
+    launch_locate(r, (const uint64_t*)d_ranges, range_stride, (const uint64_t*)d_hit_off, n, total, (uint64_t*)d_global_pos,
+                  (uint64_t*)d_pos, (hipStream_t)stream, (unsigned long long*)d_tally);
+  });
+}
+
+int awry_dev_phase_marker(awry_index_t* idx, int slot, int phase_id, void* stream) {
+  return guarded([&] {
+    replica(idx, slot);
+    require(phase_id >= 1 && phase_id <= 65535, "phase id out of range");
+    hipLaunchKernelGGL(phase_marker_kernel, dim3((unsigned)phase_id), dim3(64), 0, (hipStream_t)stream);
+    HIP_CHECK(hipGetLastError());
   });
 }
 

@@ -204,7 +204,12 @@ struct QueryList {
   unsigned long long* first_bad;    // LIST_GLOBAL (nullable): min over rejected queries of (index << 8 | status)
   uint32_t range_stride;            // LIST_GLOBAL: 1 = ranges[q] receives the range start / RS_* word only (the layout of
                                     //   the packed read kernels' range_start), otherwise (start, end) pairs
+  unsigned long long* tally;        // nullable work census (untimed runs): [0] seed probes, [1] executed steps, [2] distinct
+                                    //   blocks ranked, [3] SA reads and [4] text comparisons of seed-and-verify
 };
+__device__ __forceinline__ void tally_add(unsigned long long* tally, int slot, unsigned long long v) {
+  if (tally && v) atomicAdd(&tally[slot], v);
+}
 
 template <int A, int LIST = LIST_NONE>
 __global__ __launch_bounds__(256) void count_scalar_kernel(DevIndex ix, const uint8_t* __restrict__ ascii,
@@ -259,12 +264,14 @@ __global__ __launch_bounds__(256) void count_scalar_kernel(DevIndex ix, const ui
         }
         if (std20) {
           const SeedEntry se = ix.seed[sidx];
+          tally_add(ql.tally, 0, 1);
           const uint32_t scnt = se.cnt & AA_SEED_CNT_SAT;
           const bool wrong_sym = scnt == 1 && e - k > b && (int)(se.cnt >> 27) != (int)lut[ascii[e - k - 1]];  // BWT[row] is not the next residue
           if (ix.seed_pos && scnt == 1 && !wrong_sym) {  // position seed, as in the nucleotide branch below
             const uint64_t rem = e - k - b, p = se.sp;
             if (allow_verify && ix.text8 && rem < 65536) {
               const bool same = p >= rem && text_equals_query<A>(ix.text8 + (p - rem), ascii_bytes + b, rem, lut);
+              tally_add(ql.tally, 4, p >= rem ? 1 : 0);
               verified = true;
               vcount = same ? 1 : 0;
               vrs = same ? ((RS_SINGLE << RS_MODE_SHIFT) | (p - rem)) : ((RS_MULTI << RS_MODE_SHIFT) | (rem << 32));
@@ -291,6 +298,7 @@ __global__ __launch_bounds__(256) void count_scalar_kernel(DevIndex ix, const ui
         }
         if (acgt) {
           const SeedEntry se = ix.seed[sidx];
+          tally_add(ql.tally, 0, 1);
           const uint32_t scnt = seed_cnt(se);
           const bool wrong_sym = scnt == 1 && e - k > b && seed_sym(se) != (int)lut[ascii[e - k - 1]];  // BWT[row] is not the next symbol
           // position seeds (ix.seed_pos): a singleton entry names a text position, not a row -- good enough to reject
@@ -301,6 +309,7 @@ __global__ __launch_bounds__(256) void count_scalar_kernel(DevIndex ix, const ui
             if (allow_verify && ix.text8 && rem < 65536) {
               // (p < rem: the suffix starts too close to the text's beginning)
               const bool same = p >= rem && text_equals_query<A>(ix.text8 + (p - rem), ascii_bytes + b, rem, lut);
+              tally_add(ql.tally, 4, p >= rem ? 1 : 0);
               verified = true;
               vcount = same ? 1 : 0;
               vrs = same ? ((RS_SINGLE << RS_MODE_SHIFT) | (p - rem)) : ((RS_MULTI << RS_MODE_SHIFT) | (rem << 32));
@@ -329,7 +338,9 @@ __global__ __launch_bounds__(256) void count_scalar_kernel(DevIndex ix, const ui
           uint64_t g1 = 0;
           for (uint64_t c = 0; c < cnt; c++) {
             const uint64_t p = ix.dense_sa[sp + c];
+            tally_add(ql.tally, 3, 1);
             if (p < rem) continue;  // the suffix starts too close to the text's beginning
+            tally_add(ql.tally, 4, 1);
             if (text_equals_query<A>(ix.text8 + (p - rem), ascii_bytes + b, rem, lut)) { mask |= 1u << c; g1 = p - rem; }
           }
           verified = true;
@@ -339,6 +350,7 @@ __global__ __launch_bounds__(256) void count_scalar_kernel(DevIndex ix, const ui
           break;
         }
         i--;
+        if (ql.tally) { tally_add(ql.tally, 1, 1); tally_add(ql.tally, 2, ((sp - 1) >> 8) == (ep >> 8) ? 1 : 2); }
         step_scalar<A>(ix, sp, ep, lut[ascii[i]]);
       }
     }
@@ -460,6 +472,7 @@ __global__ __launch_bounds__(256) void count_aa_kmer_probe_kernel(DevIndex ix, c
       flags[h] = fl;
       ev[h] = SeedEntry{1u, 0u};
       if (qv[h] < n && !fl) ev[h] = seed[slot];
+      if (ql.tally) { const uint64_t pm = __ballot(qv[h] < n && !fl); if (lane == 0) tally_add(ql.tally, 0, (unsigned long long)__popcll(pm)); }
     }
     bool listed[NQ], vfy[NQ], multi[NQ];
     uint64_t value[NQ], rs[NQ], t0[NQ], t1[NQ], t2[NQ];  // rs: what the locate pass reads for the query (ranges[2q])
@@ -500,6 +513,7 @@ __global__ __launch_bounds__(256) void count_aa_kmer_probe_kernel(DevIndex ix, c
         value[h] = (((t0[h] ^ i0[h]) & m0) | ((t1[h] ^ i1[h]) & m1) | ((t2[h] ^ i2[h]) & m2)) ? 0ull : 1ull;
         if (value[h]) rs[h] = (RS_SINGLE << RS_MODE_SHIFT) | ((uint64_t)ev[h].sp - (uint64_t)rem);
       }
+      if (ql.tally) { const uint64_t vm = __ballot(vfy[h]); if (lane == 0) tally_add(ql.tally, 4, (unsigned long long)__popcll(vm)); }
       // A handful of candidate rows, neighbours in the dense SA: each is compared with the text -- two dependent loads
       // the whole wave waits for, so a wave does it only when enough of its lanes need it (a batch of k-mers from the
       // text); the odd such lane of a random batch is listed, and the second pass works through those densely.
@@ -513,6 +527,7 @@ __global__ __launch_bounds__(256) void count_aa_kmer_probe_kernel(DevIndex ix, c
 #pragma unroll
         for (int c = 0; c < AA_KMER_VMULTI; c++) p[c] = (uint32_t)c < nc ? ix.dense_sa[sp + c] : 0u;
         const uint32_t mask = candidates(p, nc, i0[h], i1[h], i2[h]);
+        if (ql.tally) { tally_add(ql.tally, 3, nc); tally_add(ql.tally, 4, nc); }
         value[h] = (uint64_t)__popc(mask);
         rs[h] = (RS_MULTI << RS_MODE_SHIFT) | (uint64_t)sp | ((uint64_t)rem << 32) | ((uint64_t)mask << 48);
       }
@@ -533,6 +548,10 @@ __global__ __launch_bounds__(256) void count_aa_kmer_probe_kernel(DevIndex ix, c
   __syncthreads();
   if (threadIdx.x == 0) ql.count[blockIdx.x] = s_count;
 }
+
+// profiling aid: an empty kernel whose grid size names a phase of a benchmark run, so that the per-dispatch rows of a
+// rocprofv3 counter pass (which cannot be combined with marker tracing on this pool) can be cut into those phases
+__global__ void phase_marker_kernel() {}
 
 // counts as 32-bit words for the trip over PCIe (host-packed paths: a count is < bwt_len < 2^32 there)
 __global__ __launch_bounds__(256) void narrow_counts_kernel(const uint64_t* __restrict__ in, uint32_t* __restrict__ out, uint64_t n) {
@@ -830,6 +849,11 @@ __global__ __launch_bounds__(256) void count_nt2_quad_kernel(DevIndex ix, const 
   }
 }
 
+// census of the quad4 kernel: tally[5] += blocks ranked by a query's steps after its first TALLY_DEEP_STEP ones.  The
+// blocks of step j of a table-less search are shared by all queries that agree on their last j letters: at most 2 * 4^j
+// lines, which stay in the Infinity Cache (256 MiB) up to j = 10 -- only the deeper steps reach HBM.
+constexpr int TALLY_DEEP_STEP = 10;
+
 // Seed-and-verify switch: compare the remaining i letters with the text instead of taking i more LF steps?
 // A single candidate is verified at once (2 lines: SA + text, against one line per remaining letter); a range of
 // 2..8 rows first takes `after` LF steps, which usually thin it out at one line each.
@@ -916,7 +940,7 @@ __global__ __launch_bounds__(256) void count_nt2_quad4_kernel(DevIndex ix, const
   int i = 0, steps_done = 0;
   int mode = 0, vj = 0;   // verify: 0 = LF steps, 1 = read SA of candidate vj, 2 = compare its text window
   uint32_t vhits = 0, vp = 0;
-  uint32_t t_probe = 0, t_step = 0, t_blk = 0, t_vsa = 0, t_vtxt = 0;
+  uint32_t t_probe = 0, t_step = 0, t_blk = 0, t_vsa = 0, t_vtxt = 0, t_deep = 0;
 
   while (__any(have)) {
     if (have) {
@@ -952,7 +976,12 @@ __global__ __launch_bounds__(256) void count_nt2_quad4_kernel(DevIndex ix, const
           i--;
           const uint32_t c = (uint32_t)(w >> (2 * i)) & 3u;
           const uint32_t cl = c == 0 ? cA : (c == 1 ? cC : (c == 2 ? cG : cT));
-          if (TALLY) { t_step++; t_blk += ((sp - 1) >> 8) == (ep >> 8) ? 1u : 2u; }
+          if (TALLY) {
+            const uint32_t nb = ((sp - 1) >> 8) == (ep >> 8) ? 1u : 2u;
+            t_step++;
+            t_blk += nb;
+            if (steps_done >= TALLY_DEEP_STEP) t_deep += nb;
+          }
           quad_step(blocks, cl, sp, ep, c, l);
           steps_done++;
         }
@@ -998,6 +1027,7 @@ __global__ __launch_bounds__(256) void count_nt2_quad4_kernel(DevIndex ix, const
     atomicAdd(&tally[0], (unsigned long long)t_probe);
     atomicAdd(&tally[1], (unsigned long long)t_step);
     atomicAdd(&tally[2], (unsigned long long)t_blk);
+    atomicAdd(&tally[5], (unsigned long long)t_deep);
     if (VERIFY) {
       atomicAdd(&tally[3], (unsigned long long)t_vsa);
       atomicAdd(&tally[4], (unsigned long long)t_vtxt);
@@ -2172,10 +2202,12 @@ __global__ __launch_bounds__(256) void nblock_sa_kernel(DevIndex ix, uint64_t ns
 // LDS_SHARE: the blocks of a wave's 64 walks are fetched cooperatively -- eight lanes per block, so that one load
 // instruction covers eight whole 128-B lines instead of 64 sixteen-byte pieces of 64 different lines (an eighth of the
 // line lookups in the texture path) -- and handed to their lanes through a wave-private LDS tile.
-template <bool LDS_SHARE>
+// TALLY: tally[0] += LF steps taken, tally[1] += hits walked (the census the roofline figure of locate is computed from).
+template <bool LDS_SHARE, bool TALLY = false>
 __global__ __launch_bounds__(256) void locate_walk_nt_lane_kernel(DevIndex ix, uint64_t total, const uint32_t* __restrict__ dense,
                                                                   uint32_t dense_ratio, uint64_t* __restrict__ gpos,
-                                                                  unsigned long long* __restrict__ batch_counter) {
+                                                                  unsigned long long* __restrict__ batch_counter,
+                                                                  unsigned long long* __restrict__ tally = nullptr) {
   constexpr int ROW = 9;  // 16-B pieces per tile row: 8 + 1 of padding against bank conflicts
   __shared__ ulonglong2 s_blk[LDS_SHARE ? 4 : 1][LDS_SHARE ? 64 * ROW : 1];
   const int lane = threadIdx.x & 63, wv_id = threadIdx.x >> 6;
@@ -2192,6 +2224,7 @@ __global__ __launch_bounds__(256) void locate_walk_nt_lane_kernel(DevIndex ix, u
   enum { IDLE = 0, FETCH = 1, WALK = 2, EMIT = 3 };
   int state = IDLE;
   uint64_t h = 0, row = 0, steps = 0;
+  unsigned long long t_steps = 0, t_hits = 0;
   for (;;) {
     const uint64_t nm = __ballot(state == IDLE);
     if (nm) {
@@ -2271,6 +2304,7 @@ __global__ __launch_bounds__(256) void locate_walk_nt_lane_kernel(DevIndex ix, u
         if (sa_bits < 64) sample &= (1ull << sa_bits) - 1;
       }
       gpos[h] = walked_position(sample, steps, bwt_len);  // src/fm_index.rs:534
+      if (TALLY) { t_steps += steps; t_hits++; }
       state = IDLE;
     } else if (state == WALK) {  // backstep, src/fm_index.rs:585-593; B[j] = {plane0[j], plane1[j]}, B[4 + j] = {plane2[j], milestone[j]}
       const uint64_t b = row >> 8;
@@ -2305,6 +2339,10 @@ __global__ __launch_bounds__(256) void locate_walk_nt_lane_kernel(DevIndex ix, u
       }
       if (stops(row)) state = EMIT;
     }
+  }
+  if (TALLY && tally) {
+    atomicAdd(&tally[0], t_steps);
+    atomicAdd(&tally[1], t_hits);
   }
 }
 

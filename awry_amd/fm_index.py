@@ -392,6 +392,10 @@ class FmIndex:
         """n ASCII queries of `length` bytes each, back to back (amino k-mers: the two-phase schedule)"""
         _check(self._L.awry_dev_count_ascii_uniform(self._h, slot, d_qbytes, n, length, d_counts, d_status, stream))
 
+    def dev_count_ascii_uniform_tally(self, d_qbytes, n, length, d_counts, d_tally, stream=None, slot=0):
+        """amino k-mer schedule + census: d_tally[5] += (seed probes, steps, blocks ranked, SA reads, text comparisons)"""
+        _check(self._L.awry_dev_count_ascii_uniform_tally(self._h, slot, d_qbytes, n, length, d_counts, d_tally, stream))
+
     def dev_scan_counts(self, d_counts, n, d_hit_off, d_scratch, stream=None, slot=0):
         _check(self._L.awry_dev_scan_counts(self._h, slot, d_counts, n, d_hit_off, d_scratch, stream))
 
@@ -400,6 +404,14 @@ class FmIndex:
 
     def dev_locate(self, d_ranges, d_hit_off, n, total, d_gpos, d_pos=None, stream=None, slot=0, range_stride=2):
         _check(self._L.awry_dev_locate(self._h, slot, d_ranges, range_stride, d_hit_off, n, total, d_gpos, d_pos, stream))
+
+    def dev_locate_tally(self, d_ranges, d_hit_off, n, total, d_gpos, d_pos, d_tally, stream=None, slot=0, range_stride=2):
+        """dev_locate + the walk kernel's census: d_tally[2] += (LF steps, hits that walked)"""
+        _check(self._L.awry_dev_locate_tally(self._h, slot, d_ranges, range_stride, d_hit_off, n, total, d_gpos, d_pos, d_tally, stream))
+
+    def dev_phase_marker(self, phase_id, stream=None, slot=0):
+        """profiling aid: an empty kernel whose grid size names a phase in rocprofv3 counter output"""
+        _check(self._L.awry_dev_phase_marker(self._h, slot, phase_id, stream))
 
     def dev_count_nt2_long(self, d_words, n, L, d_counts, d_range_start=None, use_seed=True, stream=None, slot=0):
         _check(self._L.awry_dev_count_nt2_long(self._h, slot, d_words, n, L, d_counts, d_range_start, 1 if use_seed else 0, stream))
@@ -469,7 +481,7 @@ class FmIndex:
         n, L = q2d.shape
         d_ascii = self.dev_upload(q2d.reshape(-1), slot)
         d_words, d_counts, d_bad = self.dev_malloc(8 * n, slot), self.dev_malloc(8 * n, slot), self.dev_malloc(8, slot)
-        d_tally = self.dev_malloc(40, slot) if tally else None
+        d_tally = self.dev_malloc(64, slot) if tally else None
         try:
             self.dev_memset(d_bad, 0, 8, slot)
             self.dev_pack_nt2(d_ascii, n, L, d_words, d_bad, None, slot)
@@ -478,7 +490,7 @@ class FmIndex:
             if bad:
                 raise AwryError(ERR_INVALID_QUERY, "%d queries contain bytes outside ACGT; use parallel_count" % bad)
             if tally:
-                self.dev_memset(d_tally, 0, 40, slot)
+                self.dev_memset(d_tally, 0, 64, slot)
                 self.dev_count_nt2_tally(d_words, n, L, d_counts, d_tally, use_seed, None, slot)
             else:
                 self.dev_count_nt2(d_words, n, L, d_counts, use_seed, None, slot)

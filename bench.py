@@ -2,18 +2,31 @@
 """bench.py -- k-mer count throughput of the MI355X FM-index engine (BASELINE.json's metric).
 
     python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+    python bench.py --in-process N                         (one process, N replicas: the path a Rust caller on a node uses)
 
 One "step" = one pass of the hot path (awry_dev_count_nt2: seeded backward search over packed 31-mers)
 over one batch of synthetic queries per GPU, queries already resident in HBM.  The index is replicated
 per GPU and the query batch is sharded by rank with no data-path collective -> weak scaling.
 Rank 0 prints ONE JSON line with the roofline object (algorithmic bytes from an in-kernel work census,
-HIP-event kernel time) and, at N == 1, the CPU baseline (the oracle = C restatement of the reference's
-rayon/AVX2 path, timed on this host's cores on a bounded sample of the same batch).
+HIP-event kernel time, HBM traffic from rocprofv3 counter passes of this very run) and, at N == 1, the CPU
+baseline (the oracle = C restatement of the reference's rayon/AVX2 path, timed on this host's cores on a
+bounded sample of the same batch).  At N == 1 the line also carries every other BASELINE config at its own size
+(`variants`, `locate` = configs[2] with 100 M reads, `amino` = configs[3]), each checked against the oracle in the run.
+
+HBM traffic: after its own measurements the run starts itself again under `rocprofv3 --pmc` (one child per counter
+set: FETCH_SIZE / WRITE_SIZE / TCC hit+miss, as MI355X_MICROARCH.md prescribes) on the index it saved; the child
+replays the device-resident phases, each announced by a marker kernel whose grid size is the phase id, and the
+parent cuts the per-dispatch counter rows into phases.  traffic = 2 * FETCH_SIZE KB + WRITE_SIZE KB (gfx950).
 """
 import argparse
+import csv
+import glob
 import json
 import os
+import shutil
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -28,6 +41,8 @@ WORKLOADS = {
     "grch38": (3_100_000_000, 25, 0.05),
 }
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+AMINO_TEXT, AMINO_RECORDS, AMINO_NQ, AMINO_L = 90_000_000, 250_000, 10_000_000, 12  # BASELINE.json configs[3]
+PMC_SETS = (("fetch", ["FETCH_SIZE"]), ("write", ["WRITE_SIZE"]), ("l2", ["TCC_HIT_sum", "TCC_MISS_sum"]))
 
 
 def log(*a):
@@ -63,76 +78,218 @@ def unpack_nt2(words, L):
     return out
 
 
-def amino_benchmark(torch, dev, stream, n_text=90_000_000, nq=10_000_000, L=12):
-    """BASELINE.json configs[3]: Swiss-Prot-scale amino index (5-bit alphabet), 10 M 12-mers, count -- the two-phase
-    amino k-mer schedule (per-lane probe of the 20^k seed table + byte-text verify, generic kernel on the rest), and the
-    generic one-query-per-lane kernel alone beside it.  Device-resident ASCII, HIP events."""
-    import awry_amd
-    from tests import synth
-    text, st, hd = synth.make_text(n_text, 1, 0xA5A50004, 250_000, 0.0)
-    ix = awry_amd.FmIndex.from_text(text, 1, 8, 0, st, hd, build_device=dev.index).set_devices([dev.index])
-    out = {"text_len": n_text, "records": len(st), "query_len": L, "seed_k": ix.seed_kmer_len()}
-    for name, q2d in (("random", synth.random_queries(nq, L, 1, 3)), ("present", synth.sampled_queries(text, nq // 4, L, 4, False, 1))):
-        m = len(q2d)
-        d_q = torch.from_numpy(np.concatenate([q2d.reshape(-1), np.zeros(16, dtype=np.uint8)])).to(dev)
-        d_off = torch.arange(m + 1, dtype=torch.int64, device=dev) * L
-        d_c = torch.zeros(m, dtype=torch.int64, device=dev)
-        d_g = torch.zeros(m, dtype=torch.int64, device=dev)
+class Ctx:
+    """what every measurement needs: the device, the stream the kernels run on, and the phase markers"""
 
-        def timed(fn, reps=3):
-            for _ in range(2):
-                fn()
-            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            a.record()
-            for _ in range(reps):
-                fn()
-            b.record()
-            torch.cuda.synchronize()
-            return a.elapsed_time(b) / reps
+    def __init__(self, torch, dev, child=False):
+        self.torch, self.dev, self.child = torch, dev, child
+        self.stream = torch.cuda.current_stream().cuda_stream
+        self.phases = {}  # name -> {"id": marker grid size, "launches": launches of the measured op inside the phase}
+        self.ix = None    # the index whose replica queues the markers
 
-        ms = timed(lambda: ix.dev_count_ascii_uniform(d_q.data_ptr(), m, L, d_c.data_ptr(), None, stream, 0))
-        ms_g = timed(lambda: ix.dev_count_ascii(d_q.data_ptr(), d_off.data_ptr(), m, d_g.data_ptr(), None, None, stream, 0))
-        assert torch.equal(d_c, d_g), "the amino k-mer schedule and the generic kernel disagree"
-        if name == "present":
-            assert bool((d_c >= 1).all()), "a 12-mer sampled from the text was not found"
-        out[name] = {"queries": m, "queries_per_s": m / (ms * 1e-3), "kernel_ms": ms,
-                     "generic_kernel_queries_per_s": m / (ms_g * 1e-3)}
-    return out
+    def phase(self, name, launches):
+        pid = len(self.phases) + 1
+        self.phases[name] = {"id": pid, "launches": launches}
+        self.ix.dev_phase_marker(pid, self.stream, 0)
 
+    def end_phase(self):
+        self.ix.dev_phase_marker(60000, self.stream, 0)  # whatever follows belongs to no phase
 
-def locate_benchmark(ix, text, torch, dev, stream, n_reads, read_len, oi=None, cores=1):
-    """SA-locate hits/s (BASELINE.json's second metric; configs[2] shape: reads sampled from the text, exact match).
-    Pipeline on the device: packed reads -> seeded quad count (+range starts) -> scan -> tile locate.  Timed per phase
-    with HIP events, for the file's row samples (ratio 8, mean ~7 LF steps per hit) and for the dense device SA."""
-    from tests import synth
-    ix.set_verify(-1)  # the default policy keeps the accelerators resident; measure the plain pipelines first
-    ix.set_locate_sa_ratio(0)
-    reads = synth.sampled_queries(text, n_reads, read_len, 4242)
-    W = (read_len + 31) // 32
-    d_ascii = torch.from_numpy(reads.reshape(-1)).to(dev)
-    d_words = torch.zeros(n_reads * W, dtype=torch.int64, device=dev)
-    d_bad = torch.zeros(1, dtype=torch.int64, device=dev)
-    d_counts = torch.zeros(n_reads, dtype=torch.int64, device=dev)
-    d_sp = torch.zeros(n_reads, dtype=torch.int64, device=dev)
-    d_off = torch.zeros(n_reads + 1, dtype=torch.int64, device=dev)
-    d_scr = torch.zeros(ix.dev_scan_scratch_bytes(n_reads) // 8 + 1, dtype=torch.int64, device=dev)
-    ix.dev_pack_nt2(d_ascii.data_ptr(), n_reads, read_len, d_words.data_ptr(), d_bad.data_ptr(), stream, 0)
-    torch.cuda.synchronize()
-    assert int(d_bad.item()) == 0
-
-    def timed(fn, reps=3):
-        fn()
-        torch.cuda.synchronize()
+    def timed(self, name, fn, warm=2, reps=3):
+        """ms per call of fn (HIP events on the kernels' stream) over `reps` calls after `warm`; all of them inside phase `name`"""
+        torch = self.torch
+        self.phase(name, warm + reps)
+        for _ in range(warm):
+            fn()
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
         for _ in range(reps):
             fn()
         b.record()
         torch.cuda.synchronize()
+        self.end_phase()
         return a.elapsed_time(b) / reps
 
-    ms_count = timed(lambda: ix.dev_count_nt2_long(d_words.data_ptr(), n_reads, read_len, d_counts.data_ptr(), d_sp.data_ptr(), True, stream, 0))
-    ms_scan = timed(lambda: ix.dev_scan_counts(d_counts.data_ptr(), n_reads, d_off.data_ptr(), d_scr.data_ptr(), stream, 0))
+
+def device_sampled_reads(torch, text_d, n_reads, L, seed, amb):
+    """n_reads windows of L symbols drawn from the device copy of the text at uniform positions, windows holding the
+    ambiguity letter (or the sentinel) skipped -- SURVEY.md 8(d) C3's reads, generated where they are used"""
+    gen = torch.Generator(device=text_d.device)
+    gen.manual_seed(seed)
+    n = text_d.numel() - 1
+    out = torch.empty((n_reads, L), dtype=torch.uint8, device=text_d.device)
+    ar = torch.arange(L, device=text_d.device)
+    filled, chunk = 0, 4_000_000
+    while filled < n_reads:
+        m = min(chunk, n_reads - filled)
+        pos = torch.randint(0, n - L, (m + m // 8 + 64,), device=text_d.device, generator=gen)
+        win = text_d[pos[:, None] + ar[None, :]]
+        win = win[~(win == amb).any(dim=1)]
+        k = min(win.shape[0], n_reads - filled)
+        out[filled:filled + k] = win[:k]
+        filled += k
+        del pos, win
+    return out
+
+
+def attach_traffic(entry, ms, pmc, phase):
+    """adds {traffic (HBM bytes per launch from the counter passes), traffic_GBs, traffic_frac_of_peak, l2 hit rate} to a variant"""
+    t = (pmc or {}).get(phase)
+    entry["traffic"] = t["traffic_bytes_per_launch"] if t else None
+    if t:
+        entry["traffic_GBs"] = t["traffic_bytes_per_launch"] / (ms * 1e-3) / 1e9
+        entry["traffic_frac_of_peak"] = entry["traffic_GBs"] / HBM_PEAK_GBS
+        entry["traffic_source"] = t["source"]
+        if t.get("tcc_hit_per_launch") is not None:
+            entry["l2_misses_per_launch"] = t["tcc_miss_per_launch"]
+            entry["l2_hit_rate"] = t["tcc_hit_per_launch"] / max(1.0, t["tcc_hit_per_launch"] + t["tcc_miss_per_launch"])
+    return entry
+
+
+# ------------------------------------------------------------------------------------------------ device-resident legs
+def run_variants(ctx, ix, text, batches, nq, L, counts, tally, oi, cores):
+    """the same index, other batches (N = 1): no seed table, k-mers drawn from the text (default and LF-only), ASCII resident"""
+    torch, dev, stream = ctx.torch, ctx.dev, ctx.stream
+    from tests import synth
+    extra = {}
+    nb = len(batches)
+
+    def step(i, seeded):
+        ix.dev_count_nt2(batches[i % nb].data_ptr(), nq, L, counts.data_ptr(), seeded, stream, 0)
+
+    # the batch without the seed table (the reference's step schedule: every step executed)
+    it = iter(range(1000))
+    ms = ctx.timed("unseeded", lambda: step(next(it), False), 3, 5)
+    tally.zero_()
+    for i in range(5):
+        ix.dev_count_nt2_tally(batches[i % nb].data_ptr(), nq, L, counts.data_ptr(), tally.data_ptr(), False, stream, 0)
+    torch.cuda.synchronize()
+    t = [int(x) / 5 for x in tally.cpu().tolist()]
+    s2, b2, deep = t[1], t[2], t[5]
+    ab_all, ab_deep = 104.0 * b2 + nq * 16.0, 104.0 * deep + nq * 16.0
+    extra["unseeded"] = {"queries_per_s": nq / (ms * 1e-3), "kernel_ms": ms, "steps_per_query": s2 / nq, "block_reads_per_query": b2 / nq,
+                         "block_reads_beyond_step_10_per_query": deep / nq,
+                         "algorithmic_GBs_all_steps": ab_all / (ms * 1e-3) / 1e9,
+                         "achieved_GBs": ab_deep / (ms * 1e-3) / 1e9, "frac": ab_deep / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "note": "frac prices only the blocks ranked after a query's first 10 steps (+ query and result words): the <= 2 * 4^j lines "
+                                 "of step j <= 10 are shared by all queries and stay in L2 / Infinity Cache; all steps priced at 104 B "
+                                 "(algorithmic_GBs_all_steps) exceed what HBM can deliver"}
+    # queries drawn from the text: present => every letter has to be matched
+    ns = min(nq, 2_000_000)
+    present = synth.sampled_queries(text, ns, L, 77)
+    d_ascii = torch.from_numpy(present.reshape(-1)).to(dev)
+    d_words = torch.zeros(ns, dtype=torch.int64, device=dev)
+    d_bad = torch.zeros(1, dtype=torch.int64, device=dev)
+    ix.dev_pack_nt2(d_ascii.data_ptr(), ns, L, d_words.data_ptr(), d_bad.data_ptr(), stream, 0)
+    torch.cuda.synchronize()
+    assert int(d_bad.item()) == 0
+    ms = ctx.timed("present", lambda: ix.dev_count_nt2(d_words.data_ptr(), ns, L, counts.data_ptr(), True, stream, 0), 2, 5)
+    assert bool((counts[:ns] >= 1).all()), "a k-mer sampled from the text was not found"
+    want_present = counts[:ns].clone()
+    tally.zero_()
+    ix.dev_count_nt2_tally(d_words.data_ptr(), ns, L, counts.data_ptr(), tally.data_ptr(), True, stream, 0)
+    torch.cuda.synchronize()
+    p3, s3, b3, v3, t3 = [int(x) for x in tally.cpu().tolist()[:5]]
+    ab = 16.0 * p3 + 104.0 * b3 + ns * 16.0 + 8.0 * v3 + 8.0 * t3
+    extra["present_queries"] = {"queries": ns, "queries_per_s": ns / (ms * 1e-3), "kernel_ms": ms,
+                                "achieved_GBs": ab / (ms * 1e-3) / 1e9, "frac": ab / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                "steps_per_query": s3 / ns, "verify_sa_reads_per_query": v3 / ns, "verify_text_windows_per_query": t3 / ns,
+                                "random_lines_per_s": (p3 + b3 + v3 + t3) / (ms * 1e-3), "seed_and_verify": bool(ix.verify_enabled())}
+    if oi is not None:  # the oracle on a sample of the same k-mers
+        nso = min(ns, 1_000_000)
+        ocounts, _ = oi.parallel_count(*synth.fixed_to_csr(present[:nso]), cores)
+        ok = bool(np.array_equal(ocounts, want_present[:nso].cpu().numpy().view(np.uint64)))
+        extra["present_queries"]["gpu_matches_oracle_on_sample"] = ok
+        extra["present_queries"]["oracle_sample"] = nso
+        assert ok, "GPU counts of k-mers from the text differ from the oracle"
+    # the same k-mers by LF steps only (seed-and-verify accelerators dropped): the contrast to the default
+    had_verify = ix.verify_enabled()
+    ix.set_verify(-1)
+    msv = ctx.timed("present_lf", lambda: ix.dev_count_nt2(d_words.data_ptr(), ns, L, counts.data_ptr(), True, stream, 0), 2, 5)
+    assert bool(torch.equal(counts[:ns], want_present)), "seed-and-verify changed a count"
+    tally.zero_()
+    ix.dev_count_nt2_tally(d_words.data_ptr(), ns, L, counts.data_ptr(), tally.data_ptr(), True, stream, 0)
+    torch.cuda.synchronize()
+    p4, s4, b4 = [int(x) for x in tally.cpu().tolist()[:3]]
+    ab = 16.0 * p4 + 104.0 * b4 + ns * 16.0
+    extra["present_queries_lf_steps_only"] = {"queries": ns, "queries_per_s": ns / (msv * 1e-3), "kernel_ms": msv, "steps_per_query": s4 / ns,
+                                              "achieved_GBs": ab / (msv * 1e-3) / 1e9, "frac": ab / (msv * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                              "identical_counts": True}
+    if had_verify:
+        ix.set_verify(2)
+    if ctx.child:
+        return extra
+    # ASCII boundary with on-device packing in the timed region (31 B/query read instead of 8 B)
+    na = min(nq, 5_000_000)
+    asc = torch.from_numpy(unpack_nt2(batches[0][:na].cpu().numpy().view(np.uint64), L).reshape(-1)).to(dev)
+    w2 = torch.zeros(na, dtype=torch.int64, device=dev)
+
+    def pack_count():
+        ix.dev_pack_nt2(asc.data_ptr(), na, L, w2.data_ptr(), d_bad.data_ptr(), stream, 0)
+        ix.dev_count_nt2(w2.data_ptr(), na, L, counts.data_ptr(), True, stream, 0)
+    extra["ascii_resident_pack_plus_count"] = {"queries": na, "queries_per_s": na / (ctx.timed("ascii_pack_count", pack_count, 5, 5) * 1e-3)}
+    c2 = torch.zeros(na, dtype=torch.int64, device=dev)
+    ms1 = ctx.timed("ascii_one_call", lambda: ix.dev_count_ascii_uniform(asc.data_ptr(), na, L, c2.data_ptr(), None, stream, 0), 5, 5)
+    assert bool(torch.equal(c2, counts[:na])), "awry_dev_count_ascii_uniform disagrees with pack + count"
+    extra["ascii_resident_one_call"] = {"queries": na, "queries_per_s": na / (ms1 * 1e-3)}
+    # the host boundary itself (SURVEY.md 8d-ii): ASCII + offsets in host memory -> awry_count_batch -> counts in host
+    # memory; PCIe-inclusive, never the bench `value`
+    import awry_amd
+    h_q = asc.cpu().numpy()
+    h_off = np.arange(na + 1, dtype=np.uint64) * np.uint64(L)
+
+    def host_median(fn, reps=8):
+        ts = []
+        for _ in range(reps):
+            tp = time.perf_counter()
+            fn()
+            ts.append(time.perf_counter() - tp)
+        return sorted(ts[1:])[len(ts[1:]) // 2]
+
+    h_counts = np.zeros(na, dtype=np.uint64)  # caller-owned counts_out, reused from call to call
+    med = host_median(lambda: ix.parallel_count_csr(h_q, h_off, h_counts))
+    assert np.array_equal(h_counts, counts[:na].cpu().numpy().view(np.uint64))
+    med_fresh = host_median(lambda: ix.parallel_count_csr(h_q, h_off))
+    h_words = batches[0][:na].cpu().numpy().view(np.uint64)
+    med_packed = host_median(lambda: ix.parallel_count_packed(h_words, L, h_counts))
+    assert np.array_equal(h_counts, counts[:na].cpu().numpy().view(np.uint64))
+    extra["host_boundary_end_to_end"] = {
+        "queries": na, "queries_per_s": na / med, "ms": med * 1e3, "host_in_GBs": h_q.nbytes / med / 1e9,
+        "fresh_result_array_queries_per_s": na / med_fresh, "caller_packed_kmers_queries_per_s": na / med_packed,
+        "host_threads": awry_amd.load_library().awry_host_threads(),
+        "note": "awry_count_batch: ASCII + offsets in host memory -> counts in host memory, PCIe-inclusive, through the Python mirror, "
+                "median of 7 after 1 warm-up; the host packs 2 bits per letter on its worker pool (8 B per 31-mer over PCIe), "
+                "counts return as 32-bit words; queries_per_s reuses the caller's result array, fresh_result_array allocates "
+                "one per call (first-touch page faults + the allocator's mmap/munmap)"}
+    return extra
+
+
+def locate_benchmark(ctx, ix, text, n_reads, read_len, oi=None, cores=1):
+    """SA-locate hits/s (BASELINE.json's second metric; configs[2]: 100 M 101-bp reads sampled from the text, exact match).
+    Pipeline on the device: packed reads -> count (+range starts) -> scan -> tile locate (-> walk -> localise).  Timed per
+    phase with HIP events, for the file's row samples (ratio 8: LF walks, tallied by the walk kernel), for the dense device
+    SA and for seed-and-verify (the default policy)."""
+    torch, dev, stream = ctx.torch, ctx.dev, ctx.stream
+    from tests import synth
+    ix.set_verify(-1)  # the default policy keeps the accelerators resident; measure the plain pipelines first
+    ix.set_locate_sa_ratio(0)
+    text_d = torch.from_numpy(np.ascontiguousarray(text)).to(dev)
+    d_reads = device_sampled_reads(torch, text_d, n_reads, read_len, 4242, ord("N"))
+    W = (read_len + 31) // 32
+    d_words = torch.zeros(n_reads * W, dtype=torch.int64, device=dev)
+    d_bad = torch.zeros(1, dtype=torch.int64, device=dev)
+    d_counts = torch.zeros(n_reads, dtype=torch.int64, device=dev)
+    d_sp = torch.zeros(n_reads, dtype=torch.int64, device=dev)
+    d_off = torch.zeros(n_reads + 1, dtype=torch.int64, device=dev)
+    d_scr = torch.zeros(ix.dev_scan_scratch_bytes(n_reads) // 8 + 1, dtype=torch.int64, device=dev)
+    d_tal = torch.zeros(8, dtype=torch.int64, device=dev)
+    ix.dev_pack_nt2(d_reads.data_ptr(), n_reads, read_len, d_words.data_ptr(), d_bad.data_ptr(), stream, 0)
+    torch.cuda.synchronize()
+    assert int(d_bad.item()) == 0
+    nh_reads = min(n_reads, 4_000_000)
+    h_reads = d_reads[:nh_reads].cpu().numpy()  # the host keeps only what the oracle and the host-boundary call need
+    ms_count = ctx.timed("locate_count_lf", lambda: ix.dev_count_nt2_long(d_words.data_ptr(), n_reads, read_len, d_counts.data_ptr(), d_sp.data_ptr(), True, stream, 0), 1, 2)
+    ms_scan = ctx.timed("locate_scan", lambda: ix.dev_scan_counts(d_counts.data_ptr(), n_reads, d_off.data_ptr(), d_scr.data_ptr(), stream, 0), 1, 2)
     total = int(d_off[-1].item())
     assert bool((d_counts >= 1).all()), "a read sampled from the text was not found"
     d_g = torch.zeros(max(total, 1), dtype=torch.int64, device=dev)
@@ -142,39 +299,58 @@ def locate_benchmark(ix, text, torch, dev, stream, n_reads, read_len, oi=None, c
     ref = None
     for ratio in (0, 1):  # 0 = the file's samples (suffix_array_compression_ratio 8), 1 = dense device SA
         ix.set_locate_sa_ratio(ratio)
-        ms = timed(lambda: ix.dev_locate(d_sp.data_ptr(), d_off.data_ptr(), n_reads, total, d_g.data_ptr(), d_p.data_ptr(), stream, 0, 1))
-        g = d_g[:total].cpu().numpy().view(np.uint64)
+        ms = ctx.timed("locate_walk" if ratio == 0 else "locate_dense",
+                       lambda: ix.dev_locate(d_sp.data_ptr(), d_off.data_ptr(), n_reads, total, d_g.data_ptr(), d_p.data_ptr(), stream, 0, 1), 1, 3)
         if ref is None:
-            ref = g.copy()
+            ref = d_g[:total].clone()
             # size-independent property at full size: every located position holds its read
-            qi = np.repeat(np.arange(n_reads), d_counts.cpu().numpy())
-            chk = np.random.default_rng(1).integers(0, total, size=min(total, 200_000))
-            win = text[g[chk].astype(np.int64)[:, None] + np.arange(read_len)[None, :]]
-            assert np.array_equal(win, reads[qi[chk]]), "a located position does not hold its read"
+            qi = torch.repeat_interleave(torch.arange(n_reads, device=dev), d_counts)
+            chk = torch.randint(0, total, (min(total, 1_000_000),), device=dev)
+            win = text_d[ref[chk][:, None] + torch.arange(read_len, device=dev)[None, :]]
+            assert bool(torch.equal(win, d_reads[qi[chk]])), "a located position does not hold its read"
+            del qi, chk, win
+            # the walk kernel's own census of this launch (same kernel, TALLY instantiation, untimed)
+            d_tal.zero_()
+            ix.dev_locate_tally(d_sp.data_ptr(), d_off.data_ptr(), n_reads, total, d_g.data_ptr(), d_p.data_ptr(), d_tal.data_ptr(), stream, 0, 1)
+            torch.cuda.synchronize()
+            assert bool(torch.equal(d_g[:total], ref))
+            lf_steps, walked = [int(x) for x in d_tal.cpu().tolist()[:2]]
+            steps = lf_steps / max(total, 1)
         else:
-            assert np.array_equal(ref, g), "dense-SA locate differs from the sampled-SA locate"
-        steps = 7.0 if ratio == 0 else 0.0  # mean LF steps per hit with row sampling at ratio 8
-        alg = total * (104.0 * steps + 8.0 + 16.0)
+            assert bool(torch.equal(ref, d_g[:total])), "dense-SA locate differs from the sampled-SA locate"
+            steps, lf_steps, walked = 0.0, 0, 0
+        alg = total * (8.0 + 16.0) + 104.0 * lf_steps  # 104 B per backstep + 8 B SA read + 16 B result
         out["sa_ratio_%d" % ix.locate_sa_ratio()] = {
-            "locate_kernel_ms": ms, "hits_per_s": total / (ms * 1e-3), "algorithmic_GBs": alg / (ms * 1e-3) / 1e9,
-            "frac_of_hbm_peak": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "locate_kernel_ms": ms, "hits_per_s": total / (ms * 1e-3), "backsteps_per_hit_tallied": steps, "hits_that_walked": walked,
+            "algorithmic_GBs": alg / (ms * 1e-3) / 1e9, "frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
             "end_to_end_reads_per_s_device_resident": n_reads / ((ms_count + ms_scan + ms) * 1e-3)}
     # seed-and-verify: dense SA + 4-bit text resident; the rest of a read is compared with the text, not LF-stepped
     tv = time.time()
     ix.set_verify(2)
     build_s = time.time() - tv
-    ms_count_v = timed(lambda: ix.dev_count_nt2_long(d_words.data_ptr(), n_reads, read_len, d_counts.data_ptr(), d_sp.data_ptr(), True, stream, 0))
-    ms_scan_v = timed(lambda: ix.dev_scan_counts(d_counts.data_ptr(), n_reads, d_off.data_ptr(), d_scr.data_ptr(), stream, 0))
+    ms_count_v = ctx.timed("locate_count_sv", lambda: ix.dev_count_nt2_long(d_words.data_ptr(), n_reads, read_len, d_counts.data_ptr(), d_sp.data_ptr(), True, stream, 0), 1, 3)
+    ix.dev_scan_counts(d_counts.data_ptr(), n_reads, d_off.data_ptr(), d_scr.data_ptr(), stream, 0)
     assert int(d_off[-1].item()) == total
-    ms_loc_v = timed(lambda: ix.dev_locate(d_sp.data_ptr(), d_off.data_ptr(), n_reads, total, d_g.data_ptr(), d_p.data_ptr(), stream, 0, 1))
-    assert np.array_equal(ref, d_g[:total].cpu().numpy().view(np.uint64)), "seed-and-verify locate differs"
+    ms_loc_v = ctx.timed("locate_sv", lambda: ix.dev_locate(d_sp.data_ptr(), d_off.data_ptr(), n_reads, total, d_g.data_ptr(), d_p.data_ptr(), stream, 0, 1), 1, 3)
+    assert bool(torch.equal(ref, d_g[:total])), "seed-and-verify locate differs"
+    # per read: W query words + 16 B probe + ceil((L - k) / 2) B of 4-bit text (position seeds: no SA read) + count and range words
+    alg_c = n_reads * (W * 8.0 + 16.0 + (read_len - ix.seed_kmer_len()) / 2.0 + 16.0)
+    alg_l = total * (8.0 + 16.0)
     out["seed_and_verify"] = {"count_phase_ms": ms_count_v, "count_phase_reads_per_s": n_reads / (ms_count_v * 1e-3),
+                              "count_phase_algorithmic_GBs": alg_c / (ms_count_v * 1e-3) / 1e9,
+                              "count_phase_frac": alg_c / (ms_count_v * 1e-3) / 1e9 / HBM_PEAK_GBS,
                               "locate_kernel_ms": ms_loc_v, "hits_per_s": total / (ms_loc_v * 1e-3),
-                              "end_to_end_reads_per_s_device_resident": n_reads / ((ms_count_v + ms_scan_v + ms_loc_v) * 1e-3),
+                              "frac": alg_l / (ms_loc_v * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                              "end_to_end_reads_per_s_device_resident": n_reads / ((ms_count_v + ms_scan + ms_loc_v) * 1e-3),
                               "accelerator_build_s": build_s, "identical_locations": True}
+    off_h = d_off[:nh_reads + 1].cpu().numpy().view(np.uint64)
+    ref_h = ref[:int(off_h[-1])].cpu().numpy().view(np.uint64)
+    del text_d, d_reads, d_words, d_g, d_p, ref
+    torch.cuda.empty_cache()
+    if ctx.child:
+        return out
     # the host boundary (parallel_locate: ASCII reads in host memory -> offsets + positions in host memory), PCIe-inclusive
-    nh_reads = min(n_reads, 4_000_000)
-    qb, qo = synth.fixed_to_csr(reads[:nh_reads])
+    qb, qo = synth.fixed_to_csr(h_reads)
     times, times_g = [], []
     for rep in range(4):
         tp = time.perf_counter()
@@ -185,7 +361,7 @@ def locate_benchmark(ix, text, torch, dev, stream, n_reads, read_len, oi=None, c
         hoff2, hg2, _ = ix.parallel_locate_csr(qb, qo, want_pos=False)
         times_g.append(time.perf_counter() - tp)
     nhh = int(hoff[-1])
-    assert np.array_equal(hg, ref[:nhh]), "host-boundary locate differs from the device-resident pipeline"
+    assert np.array_equal(hoff, off_h) and np.array_equal(hg, ref_h[:nhh]), "host-boundary locate differs from the device-resident pipeline"
     assert np.array_equal(hoff2, hoff) and np.array_equal(hg2, hg)
     dt, dtg = sorted(times[1:])[1], sorted(times_g[1:])[1]
     out["host_boundary_end_to_end"] = {"reads": nh_reads, "hits": nhh, "ms": dt * 1e3, "reads_per_s": nh_reads / dt,
@@ -194,14 +370,13 @@ def locate_benchmark(ix, text, torch, dev, stream, n_reads, read_len, oi=None, c
                                                "the host; positions_only passes hits_out = NULL (8 B per hit back instead of 24)"}
     del hoff, hg, hoff2, hg2
     if oi is not None:
-        ns = min(n_reads, 200_000)
-        qb, qo = synth.fixed_to_csr(reads[:ns])
+        ns = min(nh_reads, 200_000)
+        qb, qo = synth.fixed_to_csr(h_reads[:ns])
         tp = time.perf_counter()
         ooff, ogpos, opos, otally = oi.parallel_locate(qb, qo, cores)
         dt = time.perf_counter() - tp
         nh = int(ooff[-1])
-        off_gpu = d_off[:ns + 1].cpu().numpy().view(np.uint64)
-        parity = bool(np.array_equal(off_gpu, ooff) and np.array_equal(ref[:nh], ogpos))
+        parity = bool(np.array_equal(off_h[:ns + 1], ooff) and np.array_equal(ref_h[:nh], ogpos))
         out["cpu_baseline"] = {"hits_per_s": nh / dt, "reads_per_s": ns / dt, "cores": cores, "kind": "port",
                                "sample": "first %d reads, %d hits, %.1f s" % (ns, nh, dt),
                                "backsteps_per_hit": otally["backsteps"] / max(nh, 1), "steps_per_read": otally["steps"] / ns,
@@ -210,6 +385,180 @@ def locate_benchmark(ix, text, torch, dev, stream, n_reads, read_len, oi=None, c
     return out
 
 
+def amino_benchmark(ctx, ix, text, oi=None, cores=1, nq=AMINO_NQ, L=AMINO_L):
+    """BASELINE.json configs[3]: Swiss-Prot-scale amino index (5-bit alphabet), 10 M 12-mers, count -- the two-phase
+    amino k-mer schedule (per-lane probe of the 20^k seed table + byte-text verify, generic kernel on the rest), and the
+    generic one-query-per-lane kernel alone beside it.  Device-resident ASCII, HIP events; a sample of each batch is
+    counted by the oracle."""
+    torch, dev, stream = ctx.torch, ctx.dev, ctx.stream
+    from tests import synth
+    text = np.asarray(text)
+    out = {"text_len": len(text) - 1, "records": AMINO_RECORDS, "query_len": L, "seed_k": ix.seed_kmer_len()}
+    d_tal = torch.zeros(8, dtype=torch.int64, device=dev)
+    for name, q2d in (("random", synth.random_queries(nq, L, 1, 3)), ("present", synth.sampled_queries(text, nq // 4, L, 4, False, 1))):
+        m = len(q2d)
+        d_q = torch.from_numpy(np.concatenate([q2d.reshape(-1), np.zeros(16, dtype=np.uint8)])).to(dev)
+        d_off = torch.arange(m + 1, dtype=torch.int64, device=dev) * L
+        d_c = torch.zeros(m, dtype=torch.int64, device=dev)
+        d_g = torch.zeros(m, dtype=torch.int64, device=dev)
+        ms = ctx.timed("amino_" + name, lambda: ix.dev_count_ascii_uniform(d_q.data_ptr(), m, L, d_c.data_ptr(), None, stream, 0), 2, 5)
+        ms_g = ctx.timed("amino_generic_" + name, lambda: ix.dev_count_ascii(d_q.data_ptr(), d_off.data_ptr(), m, d_g.data_ptr(), None, None, stream, 0), 1, 3)
+        assert torch.equal(d_c, d_g), "the amino k-mer schedule and the generic kernel disagree"
+        if name == "present":
+            assert bool((d_c >= 1).all()), "a 12-mer sampled from the text was not found"
+        d_tal.zero_()
+        ix.dev_count_ascii_uniform_tally(d_q.data_ptr(), m, L, d_g.data_ptr(), d_tal.data_ptr(), stream, 0)
+        torch.cuda.synchronize()
+        assert torch.equal(d_c, d_g)
+        probes, steps, blocks, vsa, vtxt = [int(x) for x in d_tal.cpu().tolist()[:5]]
+        # SURVEY.md 8(d): 16 B per probe, 168 B per ranked amino block, L query bytes + 8 B result, 8 B per SA read, L - k text bytes
+        alg = 16.0 * probes + 168.0 * blocks + m * (L + 8.0) + 8.0 * vsa + (L - ix.seed_kmer_len()) * vtxt
+        out[name] = {"queries": m, "queries_per_s": m / (ms * 1e-3), "kernel_ms": ms, "generic_kernel_queries_per_s": m / (ms_g * 1e-3),
+                     "census": {"seed_probes": probes, "steps": steps, "block_reads": blocks, "verify_sa_reads": vsa, "verify_text_windows": vtxt},
+                     "achieved_GBs": alg / (ms * 1e-3) / 1e9, "frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        if oi is not None:
+            nso = min(m, 1_000_000)
+            tp = time.perf_counter()
+            ocounts, _ = oi.parallel_count(*synth.fixed_to_csr(q2d[:nso]), cores)
+            dt = time.perf_counter() - tp
+            ok = bool(np.array_equal(ocounts, d_c[:nso].cpu().numpy().view(np.uint64)))
+            out[name]["gpu_matches_oracle_on_sample"] = ok
+            out[name]["oracle_sample"] = nso
+            out[name]["cpu_oracle_queries_per_s"] = nso / dt
+            assert ok, "GPU amino counts differ from the oracle on the sample (%s)" % name
+        del d_q, d_off, d_c, d_g
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ PMC passes
+def parse_pmc_dir(d, phases):
+    """rocprofv3 counter_collection.csv of one pass -> {phase name: {counter: sum over the phase's dispatches, kernels: {...}}}"""
+    by_id = {v["id"]: k for k, v in phases.items()}
+    rows = []
+    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        with open(f, newline="") as fh:
+            rows += list(csv.DictReader(fh))
+    rows.sort(key=lambda r: int(r["Dispatch_Id"]))
+    cur, out = None, {}
+    for r in rows:
+        name = r["Kernel_Name"]
+        if "phase_marker_kernel" in name:
+            cur = by_id.get(int(r["Grid_Size"]) // 64)
+            continue
+        if cur is None:
+            continue
+        e = out.setdefault(cur, {"counters": {}, "kernels": {}})
+        v = float(r["Counter_Value"])
+        e["counters"][r["Counter_Name"]] = e["counters"].get(r["Counter_Name"], 0.0) + v
+        short = name.split("(")[0].replace("awry::", "").replace("(anonymous namespace)::", "").replace("void ", "")
+        k = e["kernels"].setdefault(short, {})
+        k[r["Counter_Name"]] = k.get(r["Counter_Name"], 0.0) + v
+    return out
+
+
+def collect_pmc(args, state_path, tmpdir):
+    """runs this script again under rocprofv3 --pmc, once per counter set; -> {phase: traffic entry} or {} when rocprofv3 is missing / fails"""
+    rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rocprof):
+        log("rocprofv3 not found: no live counter passes")
+        return {}
+    phase_file = os.path.join(tmpdir, "phases.json")
+    per_phase = {}
+    env = dict(os.environ, TMPDIR="/tmp")
+    for tag, counters in PMC_SETS:
+        d = os.path.join(tmpdir, "pmc_" + tag)
+        cmd = [rocprof, "--pmc"] + counters + ["--kernel-trace", "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__),
+               "--pmc-child", state_path, "--phase-file", phase_file, "--steps", str(min(args.steps, 5)), "--warmup", "2",
+               "--queries", str(args.queries), "--qlen", str(args.qlen), "--locate-reads", str(args.locate_reads), "--workload", args.workload]
+        if args.no_variants:
+            cmd.append("--no-variants")
+        ts = time.time()
+        try:
+            p = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=args.pmc_timeout)
+        except subprocess.TimeoutExpired:
+            log("counter pass %s timed out after %d s: no further passes" % (tag, args.pmc_timeout))
+            break
+        if p.returncode != 0:
+            log("counter pass %s failed (rc %d): %s" % (tag, p.returncode, p.stderr.decode(errors="replace")[-600:]))
+            break
+        phases = json.load(open(phase_file))
+        parsed = parse_pmc_dir(d, phases)
+        log("counter pass %s: %.0f s, %d phases" % (tag, time.time() - ts, len(parsed)))
+        for name, e in parsed.items():
+            tgt = per_phase.setdefault(name, {"launches": phases[name]["launches"], "counters": {}, "kernels": {}})
+            tgt["counters"].update(e["counters"])
+            for k, v in e["kernels"].items():
+                tgt["kernels"].setdefault(k, {}).update(v)
+        if args.keep_pmc:
+            os.makedirs(args.keep_pmc, exist_ok=True)
+            for f in glob.glob(os.path.join(d, "**", "*.csv"), recursive=True):
+                if "counter_collection" in f or "kernel_trace" in f:
+                    shutil.copy(f, os.path.join(args.keep_pmc, "%s_%s" % (tag, os.path.basename(f).split("_", 1)[1])))
+        shutil.rmtree(d, ignore_errors=True)
+    out = {}
+    for name, e in per_phase.items():
+        c, n = e["counters"], max(1, e["launches"])
+        if "FETCH_SIZE" not in c or "WRITE_SIZE" not in c:
+            continue
+        out[name] = {"traffic_bytes_per_launch": (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0 / n,
+                     "FETCH_SIZE_KB_per_launch": c["FETCH_SIZE"] / n, "WRITE_SIZE_KB_per_launch": c["WRITE_SIZE"] / n,
+                     "tcc_hit_per_launch": c["TCC_HIT_sum"] / n if "TCC_HIT_sum" in c else None,
+                     "tcc_miss_per_launch": c["TCC_MISS_sum"] / n if "TCC_MISS_sum" in c else None,
+                     "launches": n, "kernels": {k: {cn: cv / n for cn, cv in v.items()} for k, v in e["kernels"].items()},
+                     "source": "rocprofv3 --pmc child passes of this run (2*FETCH_SIZE + WRITE_SIZE KB, gfx950 correction)"}
+    return out
+
+
+def committed_traffic():
+    """fallback when the live passes are unavailable: the committed passes of the same phases (profiles/traffic.json)"""
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+        return {k: dict(v, source=v.get("source", "profiles/traffic.json")) for k, v in t.get("phases", {}).items()}
+    except (OSError, ValueError):
+        return {}
+
+
+def pmc_child(args):
+    """the run under rocprofv3 --pmc: loads what the parent saved and replays the device-resident phases"""
+    import torch
+    import awry_amd
+    st = json.load(open(args.pmc_child))
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    ctx = Ctx(torch, dev, child=True)
+    L, nq, K, W = args.qlen, args.queries, args.steps, args.warmup
+    ix = awry_amd.FmIndex.load(st["index"]).set_devices([0])
+    if st["seed_k"] != ix.seed_kmer_len():
+        ix.set_seed_kmer_len(st["seed_k"])
+    ctx.ix = ix
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1234)
+    n_batches = max(1, min(K + W, 8))
+    batches = [torch.randint(0, 1 << (2 * L), (nq,), dtype=torch.int64, device=dev, generator=gen) for _ in range(n_batches)]
+    counts = torch.zeros(nq, dtype=torch.int64, device=dev)
+    tally = torch.zeros(8, dtype=torch.int64, device=dev)
+    ctx.phase("headline", W + K)
+    for i in range(W + K):
+        ix.dev_count_nt2(batches[i % n_batches].data_ptr(), nq, L, counts.data_ptr(), True, ctx.stream, 0)
+    torch.cuda.synchronize()
+    ctx.end_phase()
+    if not args.no_variants:
+        text = np.load(st["text"], mmap_mode="r")
+        run_variants(ctx, ix, text, batches, nq, L, counts, tally, None, 1)
+        del batches, counts
+        torch.cuda.empty_cache()
+        locate_benchmark(ctx, ix, text, args.locate_reads, 101)
+        if st.get("amino_index"):
+            ix.close()
+            torch.cuda.empty_cache()
+            ax = awry_amd.FmIndex.load(st["amino_index"]).set_devices([0])
+            ctx.ix = ax
+            amino_benchmark(ctx, ax, np.load(st["amino_text"], mmap_mode="r"))
+    torch.cuda.synchronize()
+    json.dump(ctx.phases, open(args.phase_file, "w"))
+
+
+# ------------------------------------------------------------------------------------------------ main
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -222,9 +571,21 @@ def main():
     ap.add_argument("--seed-k", type=int, default=-1, help="device seed-table k (-1 = library default, 0 = off)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline duration (0 = skip)")
     ap.add_argument("--no-variants", action="store_true")
-    ap.add_argument("--locate-reads", type=int, default=20_000_000, help="101-bp reads in the locate measurement (N=1; BASELINE configs[2] has 100 M)")
+    ap.add_argument("--locate-reads", type=int, default=100_000_000, help="101-bp reads in the locate measurement (N=1): BASELINE configs[2] has 100 M")
     ap.add_argument("--sweep-seed-k", default="", help="comma list of seed k to time on rank 0 before the run (stderr)")
+    ap.add_argument("--amino", action="store_true", help="run the amino leg (configs[3]) with any workload (default: with grch38)")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 counter passes (traffic falls back to profiles/traffic.json)")
+    ap.add_argument("--pmc-timeout", type=int, default=300, help="seconds one counter pass may take")
+    ap.add_argument("--keep-pmc", default="", help="directory that receives the counter CSVs of the live passes")
+    ap.add_argument("--pmc-child", default="", help=argparse.SUPPRESS)
+    ap.add_argument("--phase-file", default="", help=argparse.SUPPRESS)
+    ap.add_argument("--in-process", type=int, default=0, help="one process, this many replicas (awry_set_devices): times the host batch entry points")
     args = ap.parse_args()
+    if args.pmc_child:
+        return pmc_child(args)
+    if args.in_process:
+        from tools import bench_in_process
+        return bench_in_process.main(args)
 
     import torch
     import torch.distributed as dist
@@ -256,20 +617,40 @@ def main():
     if args.text_len:
         n_text = args.text_len
     L, nq, K, W = args.qlen, args.queries, args.steps, args.warmup
+    shm = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else "/tmp"
+    tmpdir = tempfile.mkdtemp(prefix="awry_bench_", dir=shm) if rank == 0 else None
+    index_path = None
+    want_pmc = not args.no_pmc and world == 1
 
-    # ---- index: same seeded text on every rank, one replica in this rank's HBM
+    # ---- index: built ONCE (rank 0, on its GPU) and handed to the other ranks as an .awry v1 file; every rank then
+    #      replicates it into its own GPU's HBM and builds its seed table / accelerators there, concurrently
     t0 = time.time()
-    text, starts, headers = synth.make_text(n_text, 0, 0xA5A50000 + 2, n_rec, n_frac)
-    t1 = time.time()
-    ix = awry_amd.FmIndex.from_text(text, 0, 8, 0, starts, headers, build_device=local_rank)  # each rank builds on its own GPU
+    text = None
+    if rank == 0:
+        text, starts, headers = synth.make_text(n_text, 0, 0xA5A50000 + 2, n_rec, n_frac)
+        t1 = time.time()
+        ix = awry_amd.FmIndex.from_text(text, 0, 8, 0, starts, headers, build_device=local_rank)
+        t2 = time.time()
+        index_path = os.path.join(tmpdir, "index.awry")
+        if world > 1 or args.cpu_seconds > 0 or want_pmc:
+            ix.save(index_path)  # .awry v1 in the reference's own layout: 160-B blocks, packed SA, k-mer table
+        log("text %.1fs, index build %.1fs, save %.1fs" % (t1 - t0, t2 - t1, time.time() - t2))
+    if world > 1:
+        box = [index_path]
+        dist.broadcast_object_list(box, src=0)
+        index_path = box[0]
+        if rank != 0:
+            ix = awry_amd.FmIndex.load(index_path)
     t2 = time.time()
     ix.set_devices([local_rank])
     if args.seed_k >= 0:
         ix.set_seed_kmer_len(args.seed_k)
     t3 = time.time()
     if rank == 0:
-        log("text %.1fs, host index build %.1fs, replicate+seed(k=%d) %.1fs, bwt_len=%d" %
-            (t1 - t0, t2 - t1, ix.seed_kmer_len(), t3 - t2, ix.bwt_len()))
+        log("replicate+seed(k=%d)+accelerators %.1fs, bwt_len=%d" % (ix.seed_kmer_len(), t3 - t2, ix.bwt_len()))
+    ctx = Ctx(torch, dev)
+    ctx.ix = ix
+    stream = ctx.stream
 
     # ---- synthetic query batches, generated on the device: a uniform random L-mer is a uniform 2L-bit integer
     gen = torch.Generator(device=dev)
@@ -277,8 +658,7 @@ def main():
     n_batches = max(1, min(K + W, 8))
     batches = [torch.randint(0, 1 << (2 * L), (nq,), dtype=torch.int64, device=dev, generator=gen) for _ in range(n_batches)]
     counts = torch.zeros(nq, dtype=torch.int64, device=dev)
-    tally = torch.zeros(5, dtype=torch.int64, device=dev)
-    stream = torch.cuda.current_stream().cuda_stream
+    tally = torch.zeros(8, dtype=torch.int64, device=dev)
 
     def step(i, seeded=True):
         ix.dev_count_nt2(batches[i % n_batches].data_ptr(), nq, L, counts.data_ptr(), seeded, stream, 0)
@@ -336,27 +716,13 @@ def main():
                                "packed 2-bit queries resident in HBM, seed table k=%d, SA ratio 8"
                                % (args.workload, n_text, n_rec, 100 * n_frac, nq, L, ix.seed_kmer_len()),
                    "text_len": n_text, "queries_per_gpu_per_step": nq, "query_len": L, "seed_k": ix.seed_kmer_len(),
-                   "sharding": "index replicated per GPU, queries sharded by rank, no collective"},
+                   "sharding": "index replicated per GPU (built once, handed over as .awry v1), queries sharded by rank, no collective"},
         "roofline": {"bound": "hbm", "kernel": ix.count_schedule(L), "achieved": alg_bytes / (kernel_ms * 1e-3) / 1e9,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg_bytes / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                      "traffic": None, "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": alg_bytes,
                      "census_per_launch": {"seed_probes": probes, "steps": steps_exec, "block_reads": blocks,
                                            "verify_sa_reads": vsa, "verify_text_windows": vtxt}},
     }
-
-    # HBM traffic per launch from the committed rocprofv3 PMC passes of this exact configuration (null otherwise)
-    try:
-        tkey = "%s|nq=%d|L=%d|seed_k=%d|kernel=%s" % (args.workload if not args.text_len else "custom", nq, L, ix.seed_kmer_len(), ix.count_schedule(L))
-        tentry = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get(tkey)
-        if tentry:
-            result["roofline"]["traffic"] = tentry["traffic_bytes_per_launch"]
-            result["roofline"]["traffic_source"] = tentry["source"]
-            # the HBM bytes the kernel really moves per second (PMC traffic / live kernel time): every 8-B seed entry drags a
-            # whole line, so this sits far above the algorithmic rate
-            result["roofline"]["traffic_GBs"] = tentry["traffic_bytes_per_launch"] / (kernel_ms * 1e-3) / 1e9
-            result["roofline"]["traffic_frac_of_peak"] = result["roofline"]["traffic_GBs"] / HBM_PEAK_GBS
-    except (OSError, ValueError):
-        pass
     # the ceiling that actually binds this access pattern: random 128-B line requests (profiles/r01_gather_calibration.txt)
     lines = probes + blocks + vsa + vtxt + nq * (8.0 + 8.0) / 128.0
     result["roofline"]["random_line_rate"] = {"achieved_Glines_s": lines / (kernel_ms * 1e-3) / 1e9, "measured_ceiling_Glines_s": 48.0,
@@ -378,134 +744,11 @@ def main():
         del a, b
 
     if rank == 0 and world == 1:
-        extra = {}
-        if not args.no_variants:
-            # the same batch without the seed table (the reference's step schedule minus nothing: every step executed)
-            tally.zero_()
-            for i in range(3):
-                step(i, False)
-            torch.cuda.synchronize()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for i in range(5):
-                step(i, False)
-            e1.record()
-            torch.cuda.synchronize()
-            ms = e0.elapsed_time(e1) / 5
-            for i in range(5):
-                ix.dev_count_nt2_tally(batches[i % n_batches].data_ptr(), nq, L, counts.data_ptr(), tally.data_ptr(), False, stream, 0)
-            torch.cuda.synchronize()
-            p2, s2, b2 = [int(x) / 5 for x in tally.cpu().tolist()[:3]]
-            ab = 104.0 * b2 + nq * 16.0
-            extra["unseeded"] = {"queries_per_s": nq / (ms * 1e-3), "kernel_ms": ms, "achieved_GBs": ab / (ms * 1e-3) / 1e9,
-                                 "frac": ab / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "steps_per_query": s2 / nq, "block_reads_per_query": b2 / nq,
-                                 "note": "algorithmic bytes (104 B per ranked block) can exceed the HBM peak here: the blocks of the first ~10 steps "
-                                         "of every query are shared by all queries and come from L2 / Infinity Cache"}
-            # queries drawn from the text: present => all L - k steps execute
-            ns = min(nq, 2_000_000)
-            present = synth.sampled_queries(text, ns, L, 77)
-            d_ascii = torch.from_numpy(present.reshape(-1)).to(dev)
-            d_words = torch.zeros(ns, dtype=torch.int64, device=dev)
-            d_bad = torch.zeros(1, dtype=torch.int64, device=dev)
-            ix.dev_pack_nt2(d_ascii.data_ptr(), ns, L, d_words.data_ptr(), d_bad.data_ptr(), stream, 0)
-            torch.cuda.synchronize()
-            assert int(d_bad.item()) == 0
-            for _ in range(2):
-                ix.dev_count_nt2(d_words.data_ptr(), ns, L, counts.data_ptr(), True, stream, 0)
-            e0.record()
-            for _ in range(5):
-                ix.dev_count_nt2(d_words.data_ptr(), ns, L, counts.data_ptr(), True, stream, 0)
-            e1.record()
-            torch.cuda.synchronize()
-            ms = e0.elapsed_time(e1) / 5
-            assert bool((counts[:ns] >= 1).all()), "a k-mer sampled from the text was not found"
-            tally.zero_()
-            ix.dev_count_nt2_tally(d_words.data_ptr(), ns, L, counts.data_ptr(), tally.data_ptr(), True, stream, 0)
-            torch.cuda.synchronize()
-            p3, s3, b3, v3, t3 = [int(x) for x in tally.cpu().tolist()[:5]]
-            ab = 16.0 * p3 + 104.0 * b3 + ns * 16.0 + 8.0 * v3 + 8.0 * t3
-            extra["present_queries"] = {"queries": ns, "queries_per_s": ns / (ms * 1e-3), "kernel_ms": ms,
-                                        "achieved_GBs": ab / (ms * 1e-3) / 1e9, "frac": ab / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                        "steps_per_query": s3 / ns, "verify_sa_reads_per_query": v3 / ns,
-                                        "verify_text_windows_per_query": t3 / ns,
-                                        "random_lines_per_s": (p3 + b3 + v3 + t3) / (ms * 1e-3)}
-            # the same present k-mers by LF steps only (seed-and-verify accelerators dropped): the contrast to the default
-            want_present = counts[:ns].clone()
-            had_verify = ix.verify_enabled()
-            ix.set_verify(-1)
-            for _ in range(2):
-                ix.dev_count_nt2(d_words.data_ptr(), ns, L, counts.data_ptr(), True, stream, 0)
-            e0.record()
-            for _ in range(5):
-                ix.dev_count_nt2(d_words.data_ptr(), ns, L, counts.data_ptr(), True, stream, 0)
-            e1.record()
-            torch.cuda.synchronize()
-            msv = e0.elapsed_time(e1) / 5
-            assert bool(torch.equal(counts[:ns], want_present)), "seed-and-verify changed a count"
-            extra["present_queries"]["seed_and_verify"] = bool(had_verify)
-            extra["present_queries_lf_steps_only"] = {"queries_per_s": ns / (msv * 1e-3), "kernel_ms": msv, "identical_counts": True}
-            if had_verify:
-                ix.set_verify(2)
-            # ASCII boundary with on-device packing in the timed region (31 B/query read instead of 8 B)
-            na = min(nq, 5_000_000)
-            asc = torch.from_numpy(unpack_nt2(batches[0][:na].cpu().numpy().view(np.uint64), L).reshape(-1)).to(dev)
-            w2 = torch.zeros(na, dtype=torch.int64, device=dev)
-            for rep in range(2):
-                e0.record()
-                for _ in range(5):
-                    ix.dev_pack_nt2(asc.data_ptr(), na, L, w2.data_ptr(), d_bad.data_ptr(), stream, 0)
-                    ix.dev_count_nt2(w2.data_ptr(), na, L, counts.data_ptr(), True, stream, 0)
-                e1.record()
-                torch.cuda.synchronize()
-            extra["ascii_resident_pack_plus_count"] = {"queries": na, "queries_per_s": na / (e0.elapsed_time(e1) / 5 * 1e-3)}
-            # the same through the one-call entry point (pack + packed kernels + the generic kernel over the list of
-            # queries with other letters, scratch in the replica)
-            c2 = torch.zeros(na, dtype=torch.int64, device=dev)
-            for rep in range(2):
-                e0.record()
-                for _ in range(5):
-                    ix.dev_count_ascii_uniform(asc.data_ptr(), na, L, c2.data_ptr(), None, stream, 0)
-                e1.record()
-                torch.cuda.synchronize()
-            assert bool(torch.equal(c2, counts[:na])), "awry_dev_count_ascii_uniform disagrees with pack + count"
-            extra["ascii_resident_one_call"] = {"queries": na, "queries_per_s": na / (e0.elapsed_time(e1) / 5 * 1e-3)}
-            # the host boundary itself: ASCII + offsets in host memory -> awry_count_batch -> counts in host
-            # memory; PCIe-inclusive, never the bench `value`
-            h_q = asc.cpu().numpy()
-            h_off = np.arange(na + 1, dtype=np.uint64) * np.uint64(L)
-
-            def host_median(fn, reps=8):
-                ts = []
-                for _ in range(reps):
-                    tp = time.perf_counter()
-                    fn()
-                    ts.append(time.perf_counter() - tp)
-                return sorted(ts[1:])[len(ts[1:]) // 2]
-
-            h_counts = np.zeros(na, dtype=np.uint64)  # caller-owned counts_out, reused from call to call
-            med = host_median(lambda: ix.parallel_count_csr(h_q, h_off, h_counts))
-            assert np.array_equal(h_counts, counts[:na].cpu().numpy().view(np.uint64))
-            med_fresh = host_median(lambda: ix.parallel_count_csr(h_q, h_off))
-            h_words = batches[0][:na].cpu().numpy().view(np.uint64)
-            med_packed = host_median(lambda: ix.parallel_count_packed(h_words, L, h_counts))
-            assert np.array_equal(h_counts, counts[:na].cpu().numpy().view(np.uint64))
-            extra["host_boundary_end_to_end"] = {
-                "queries": na, "queries_per_s": na / med, "ms": med * 1e3, "host_in_GBs": h_q.nbytes / med / 1e9,
-                "fresh_result_array_queries_per_s": na / med_fresh, "caller_packed_kmers_queries_per_s": na / med_packed,
-                "host_threads": awry_amd.load_library().awry_host_threads(),
-                "note": "awry_count_batch: ASCII + offsets in host memory -> counts in host memory, PCIe-inclusive, through the Python mirror, "
-                        "median of 7 after 1 warm-up; the host packs 2 bits per letter on its worker pool (8 B per 31-mer over PCIe), "
-                        "counts return as 32-bit words; queries_per_s reuses the caller's result array, fresh_result_array allocates "
-                        "one per call (first-touch page faults + the allocator's mmap/munmap)"}
-        result["variants"] = extra
-
+        oi, cores = None, 1
         if args.cpu_seconds > 0:
             from oracle import oracle_ffi
-            path = "/tmp/awry_bench_%d.awry" % os.getpid()
             ts = time.time()
-            ix.save(path)  # .awry v1 in the reference's own layout: 160-B blocks, packed SA, k-mer table
-            oi = oracle_ffi.OracleIndex.load(path)
-            os.remove(path)
+            oi = oracle_ffi.OracleIndex.load(index_path)
             log("oracle index via .awry round trip: %.1fs" % (time.time() - ts))
             cores = effective_cpus()
             sample = min(nq, 10_000_000)
@@ -537,28 +780,95 @@ def main():
                 log("PARITY FAILURE: GPU counts differ from the oracle on the sample")
                 print(json.dumps(result))
                 sys.exit(3)
-        else:
-            oi, cores = None, 1
+        state = {"index": index_path, "seed_k": ix.seed_kmer_len()}
         if not args.no_variants:
-            del batches
+            result["variants"] = run_variants(ctx, ix, text, batches, nq, L, counts, tally, oi, cores)
+            del batches, counts
             torch.cuda.empty_cache()
-            result["locate"] = locate_benchmark(ix, text, torch, dev, stream, args.locate_reads, 101, oi, cores)
-            if args.workload == "grch38":
-                del ix
-                torch.cuda.empty_cache()
-                result["amino"] = amino_benchmark(torch, dev, stream)
+            result["locate"] = locate_benchmark(ctx, ix, text, args.locate_reads, 101, oi, cores)
+            if oi is not None:
+                oi.close()
+                oi = None
+            ix.close()
+            torch.cuda.empty_cache()
+            if args.workload == "grch38" or args.amino:
+                atext, ast, ahd = synth.make_text(AMINO_TEXT, 1, 0xA5A50004, AMINO_RECORDS, 0.0)
+                ax = awry_amd.FmIndex.from_text(atext, 1, 8, 0, ast, ahd, build_device=local_rank)
+                aoi = None
+                apath = os.path.join(tmpdir, "amino.awry")
+                if args.cpu_seconds > 0 or want_pmc:
+                    ax.save(apath)
+                    state["amino_index"] = apath
+                if args.cpu_seconds > 0:
+                    from oracle import oracle_ffi
+                    aoi = oracle_ffi.OracleIndex.load(apath)
+                ax.set_devices([local_rank])
+                ctx.ix = ax
+                result["amino"] = amino_benchmark(ctx, ax, atext, aoi, cores)
+                if aoi is not None:
+                    aoi.close()
+                ax.close()
+                if want_pmc:
+                    state["amino_text"] = os.path.join(tmpdir, "amino_text.npy")
+                    np.save(state["amino_text"], atext)
+                del atext
+        else:
+            del batches, counts
+            ix.close()
+        torch.cuda.empty_cache()
+        # ---- HBM traffic of every phase from rocprofv3 counter passes of this run (children of this process, run after
+        #      it has released its HBM); falls back to the committed passes of the same phases
+        pmc = {}
+        if want_pmc:
+            state["text"] = os.path.join(tmpdir, "text.npy")
+            np.save(state["text"], text)
+            state_path = os.path.join(tmpdir, "state.json")
+            json.dump(state, open(state_path, "w"))
+            tp = time.time()
+            pmc = collect_pmc(args, state_path, tmpdir)
+            log("counter passes: %.0f s, phases with traffic: %s" % (time.time() - tp, sorted(pmc)))
+            if args.keep_pmc and pmc:
+                json.dump(pmc, open(os.path.join(args.keep_pmc, "pmc_phases.json"), "w"), indent=1)
+        if not pmc:
+            pmc = committed_traffic()
+        result["pmc_phases"] = {k: {kk: vv for kk, vv in v.items() if kk != "kernels"} for k, v in pmc.items()}
+        attach_traffic(result["roofline"], kernel_ms, pmc, "headline")
+        if "variants" in result:
+            v = result["variants"]
+            attach_traffic(v["unseeded"], v["unseeded"]["kernel_ms"], pmc, "unseeded")
+            attach_traffic(v["present_queries"], v["present_queries"]["kernel_ms"], pmc, "present")
+            attach_traffic(v["present_queries_lf_steps_only"], v["present_queries_lf_steps_only"]["kernel_ms"], pmc, "present_lf")
+            lo = result["locate"]
+            attach_traffic(lo["sa_ratio_8"], lo["sa_ratio_8"]["locate_kernel_ms"], pmc, "locate_walk")
+            attach_traffic(lo["sa_ratio_1"], lo["sa_ratio_1"]["locate_kernel_ms"], pmc, "locate_dense")
+            attach_traffic(lo["seed_and_verify"], lo["seed_and_verify"]["locate_kernel_ms"], pmc, "locate_sv")
+            cnt = attach_traffic({}, lo["seed_and_verify"]["count_phase_ms"], pmc, "locate_count_sv")
+            lo["seed_and_verify"].update({"count_phase_" + k: x for k, x in cnt.items()})
+            cnt = attach_traffic({}, lo["count_phase_ms"], pmc, "locate_count_lf")
+            lo.update({"count_phase_" + k: x for k, x in cnt.items()})
+            if "amino" in result:
+                for name in ("random", "present"):
+                    attach_traffic(result["amino"][name], result["amino"][name]["kernel_ms"], pmc, "amino_" + name)
 
     if world > 1:
         # parity re-checked at every G, outside the timed region.  All ranks count one common batch (half
-        # k-mers of the text, half random; same seeds everywhere) twice: with the default schedule (seed table, context
-        # and position seeds, text comparison) and by plain backward search from the last letter with no table and no
-        # accelerator -- the reference's own algorithm on the GPU.  The two must agree on every rank, k-mers of the text
-        # must be found, and the replicas must agree among themselves (checksums reduced with MIN / MAX).  The oracle
-        # itself is compared against at N = 1 only (cpu_baseline).
-        from tests import synth
+        # k-mers of the text, half random; made by rank 0, which holds the text, and broadcast) twice: with the default
+        # schedule (seed table, context and position seeds, text comparison) and by plain backward search from the last
+        # letter with no table and no accelerator -- the reference's own algorithm on the GPU.  The two must agree on every
+        # rank, k-mers of the text must be found, and the replicas must agree among themselves (checksums reduced with
+        # MIN / MAX).  The oracle itself is compared against at N = 1 only (cpu_baseline).
         npar = 1_000_000
-        common = np.concatenate([synth.sampled_queries(text, npar // 2, L, 4711), synth.random_queries(npar // 2, L, 0, 4712)])
-        d_ascii = torch.from_numpy(common.reshape(-1)).to(dev)
+        if rank == 0:
+            common = np.concatenate([synth.sampled_queries(text, npar // 2, L, 4711), synth.random_queries(npar // 2, L, 0, 4712)])
+            d_ascii = torch.from_numpy(common.reshape(-1)).to(dev)
+        else:
+            d_ascii = torch.empty(npar * L, dtype=torch.uint8, device=dev)
+        if backend == "nccl":
+            dist.broadcast(d_ascii, src=0)
+        else:
+            h = d_ascii.cpu()
+            dist.broadcast(h, src=0)
+            d_ascii = h.to(dev)
         d_w = torch.zeros(npar, dtype=torch.int64, device=dev)
         d_b = torch.zeros(1, dtype=torch.int64, device=dev)
         d_c = torch.zeros(npar, dtype=torch.int64, device=dev)
@@ -586,7 +896,10 @@ def main():
                 dist.destroy_process_group()
                 sys.exit(3)
 
+    if world > 1:
+        dist.barrier()
     if rank == 0:
+        shutil.rmtree(tmpdir, ignore_errors=True)
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -185,9 +185,10 @@ int awry_dev_pack_nt2(awry_index_t *idx, int slot, const void *d_ascii, uint64_t
 /* the hot kernel: count n packed k-mers -> u64 counts.  use_seed != 0 starts from the seed table */
 int awry_dev_count_nt2(awry_index_t *idx, int slot, const void *d_words, uint64_t n, int L, void *d_counts,
                        int use_seed, void *stream);
-/* same kernel with a work census for the roofline figure: d_tally[5] (u64, caller-zeroed) += {seed probes,
- * executed steps, distinct BWT blocks ranked, SA reads and text windows of seed-and-verify} -- the first three are
- * the tallies SURVEY.md 8(d) prices at 16 B / 104 B each */
+/* same kernel with a work census for the roofline figure: d_tally[6] (u64, caller-zeroed) += {seed probes,
+ * executed steps, distinct BWT blocks ranked, SA reads and text windows of seed-and-verify, blocks ranked by steps
+ * after a query's first 10 (single-kernel schedule only: the ones whose lines no longer sit in the Infinity Cache)} --
+ * the first three are the tallies SURVEY.md 8(d) prices at 16 B / 104 B each */
 int awry_dev_count_nt2_tally(awry_index_t *idx, int slot, const void *d_words, uint64_t n, int L, void *d_counts,
                              int use_seed, void *d_tally, void *stream);
 /* generic path: ASCII queries + u64 offsets[n+1] -> counts[n], optional ranges[2n] (start,end) and status[n] bytes */
@@ -200,6 +201,11 @@ int awry_dev_count_ascii(awry_index_t *idx, int slot, const void *d_qbytes, cons
  * reading query q at q * len.  Scratch lives in the replica, per stream. */
 int awry_dev_count_ascii_uniform(awry_index_t *idx, int slot, const void *d_qbytes, uint64_t n, uint64_t len,
                                  void *d_counts, void *d_status, void *stream);
+/* the amino k-mer schedule of awry_dev_count_ascii_uniform with a work census: d_tally[5] (u64, caller-zeroed) +=
+ * {seed probes, executed steps, distinct BWT blocks ranked, SA reads, text comparisons} over both of its passes
+ * (168 B per block); slower than the plain call (per-event atomics) -- for untimed runs */
+int awry_dev_count_ascii_uniform_tally(awry_index_t *idx, int slot, const void *d_qbytes, uint64_t n, uint64_t len,
+                                       void *d_counts, void *d_tally, void *stream);
 /* exclusive scan of counts[n] -> hit_off[n+1] (d_scratch: awry_dev_scan_scratch_bytes(n) bytes) */
 uint64_t awry_dev_scan_scratch_bytes(uint64_t n);
 int awry_dev_scan_counts(awry_index_t *idx, int slot, const void *d_counts, uint64_t n, void *d_hit_off,
@@ -209,6 +215,13 @@ int awry_dev_scan_counts(awry_index_t *idx, int slot, const void *d_counts, uint
  * global_pos[total], pos[total] (nullable) */
 int awry_dev_locate(awry_index_t *idx, int slot, const void *d_ranges, int range_stride, const void *d_hit_off, uint64_t n,
                     uint64_t total, void *d_global_pos, void *d_pos, void *stream);
+/* awry_dev_locate with the walk kernel's census: d_tally[2] (u64, caller-zeroed) += {LF steps taken by the walks, hits
+ * that had to walk} -- what SURVEY.md 8(d) prices at 104 B per backstep.  Nucleotide indexes. */
+int awry_dev_locate_tally(awry_index_t *idx, int slot, const void *d_ranges, int range_stride, const void *d_hit_off, uint64_t n,
+                          uint64_t total, void *d_global_pos, void *d_pos, void *d_tally, void *stream);
+/* profiling aid: queues an empty kernel (phase_marker_kernel) of phase_id blocks of 64 threads on `stream`.  rocprofv3
+ * counter passes report the grid size of every dispatch, so a run can be cut into named phases without marker tracing. */
+int awry_dev_phase_marker(awry_index_t *idx, int slot, int phase_id, void *stream);
 /* packed reads of any length: W = ceil(L/32) u64 words per query (letter j in word j/32, bits 2(j%32), as written by
  * awry_dev_pack_nt2); counts[n] and, if non-null, range_start[n] (first BWT row of each range) for awry_dev_locate */
 int awry_dev_count_nt2_long(awry_index_t *idx, int slot, const void *d_words, uint64_t n, int L, void *d_counts,

@@ -1101,7 +1101,7 @@ def test_non_canonical_text_letters(oracle, alphabet):
         c = O.orc_brute_locate(alphabet, text.ctypes.data, len(text), q, len(q), buf.ctypes.data_as(u64p), len(buf))
         want_count.append(c)
         want_pos.append(np.sort(buf[:c]))
-    for dev in (awry_amd_build_host(), 0):
+    for dev in (awry_build_host(), 0):
         ix = FmIndex.from_text(text, alphabet, 4, 0, build_device=dev).set_devices([0])
         for verify in (2, -1):
             ix.set_verify(verify)

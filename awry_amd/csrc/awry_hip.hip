@@ -970,8 +970,9 @@ void count_shard_generic(Replica& r, const uint8_t* qbytes, const uint64_t* qoff
 // outside ACGT travel as a compact CSR batch of their own and are redone on the device by the generic kernel
 // (LIST_COMPACT), overwriting their packed counts: results never depend on the path.
 // words != nullptr: the caller's k-mers are packed already (awry_count_packed_kmers): staged with a pool memcpy.
+struct NotUniform {};  // thrown by count_shard_hostpacked(assume_uniform) when a query's length differs from the assumed one
 void count_shard_hostpacked(Replica& r, const uint8_t* qbytes, const uint64_t* qoff, Shard sh, PackedPlan plan, uint64_t* counts_out,
-                            const uint64_t* words = nullptr) {
+                            const uint64_t* words = nullptr, bool assume_uniform = false) {
   const uint64_t L = plan.Lmax, W = (L + 31) / 32;
   static const bool trace = getenv("AWRY_TRACE_HOST") != nullptr;
   static const uint64_t chunk_q = [] { const char* e = getenv("AWRY_HOST_CHUNK"); return e && atoll(e) > 0 ? (uint64_t)atoll(e) : (uint64_t)(1u << 20); }();
@@ -1046,7 +1047,10 @@ void count_shard_hostpacked(Replica& r, const uint8_t* qbytes, const uint64_t* q
     ln.chunk_hi = hi;
     auto a = now();
     if (words) { pool_memcpy(ln.h_words.p, words + lo, n * 8); bad.clear(); }
-    else pack_nt2_host(qbytes + qoff[lo], qbytes + qoff[sh.hi], plan.ragged ? qoff : nullptr, lo, hi, L, ln.h_words.p, plan.ragged ? ln.h_lens.p : nullptr, bad);
+    // (assume_uniform: the chunks before this one have been checked, so qoff[lo] is where query lo starts either way)
+    else if (!pack_nt2_host(qbytes + qoff[lo], qbytes + qoff[sh.hi], plan.ragged ? qoff : nullptr, lo, hi, L, ln.h_words.p,
+                            plan.ragged ? ln.h_lens.p : nullptr, bad, assume_uniform ? qoff : nullptr))
+      throw NotUniform{};  // (the Drain guard leaves the lanes idle; the caller plans the batch again from a full length scan)
     auto b = now();
     ln.nbad = bad.size();
     HIP_CHECK(hipMemcpyAsync(ln.words.p, ln.h_words.p, n * W * 8, hipMemcpyHostToDevice, ln.s));
@@ -1290,12 +1294,28 @@ void count_shard(Replica& r, const uint8_t* qbytes, const uint64_t* qoff, Shard 
   HIP_CHECK(hipSetDevice(r.device));
   static const bool no_fast = getenv("AWRY_HOST_PATH") && !strcmp(getenv("AWRY_HOST_PATH"), "generic");
   const auto t0 = std::chrono::steady_clock::now();
+  static const bool dev_pack = getenv("AWRY_HOST_PACK") && !strcmp(getenv("AWRY_HOST_PACK"), "0");
   PackedPlan plan;
-  if (!no_fast && r.dev.alphabet == NUCLEOTIDE && r.dev.bwt_len < (1ull << 32) - 512) plan = plan_packed(qoff, sh);
+  const bool packable = !no_fast && r.dev.alphabet == NUCLEOTIDE && r.dev.bwt_len < (1ull << 32) - 512;
+  if (packable && !dev_pack && sh.hi - sh.lo >= (1u << 16)) {
+    // k-mer and read batches are nearly always of one length: assume the first query's, let the packer check the
+    // offsets in the pass that reads the bytes anyway (a separate scan of 8 B per query costs 7 % of a 31-mer batch)
+    const uint64_t n = sh.hi - sh.lo, L0 = qoff[sh.lo + 1] - qoff[sh.lo];
+    if (L0 >= 1 && L0 <= 4096 && qoff[sh.hi] >= qoff[sh.lo] && qoff[sh.hi] - qoff[sh.lo] == n * L0) {
+      PackedPlan guess;
+      guess.ok = true;
+      guess.Lmax = L0;
+      try {
+        count_shard_hostpacked(r, qbytes, qoff, sh, guess, counts_out, nullptr, true);
+        return;
+      } catch (const NotUniform&) {  // plan it properly below; what was written to counts_out is overwritten
+      }
+    }
+  }
+  if (packable) plan = plan_packed(qoff, sh);
   if (getenv("AWRY_TRACE_HOST"))
     fprintf(stderr, "[awry] length scan %.2f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
   if (plan.ok) {
-    static const bool dev_pack = getenv("AWRY_HOST_PACK") && !strcmp(getenv("AWRY_HOST_PACK"), "0");
     if (dev_pack) count_shard_packed(r, qbytes, qoff, sh, plan, counts_out);
     else count_shard_hostpacked(r, qbytes, qoff, sh, plan, counts_out);
     return;

@@ -221,12 +221,13 @@ inline bool pack_query(const uint8_t* p, uint64_t len, const uint8_t* end, uint6
 
 }  // namespace
 
-void pack_nt2_host(const uint8_t* ascii, const uint8_t* ascii_end, const uint64_t* off, uint64_t lo, uint64_t hi, uint64_t L,
-                   uint64_t* words, uint32_t* lens, std::vector<uint32_t>& bad) {
+bool pack_nt2_host(const uint8_t* ascii, const uint8_t* ascii_end, const uint64_t* off, uint64_t lo, uint64_t hi, uint64_t L,
+                   uint64_t* words, uint32_t* lens, std::vector<uint32_t>& bad, const uint64_t* check_off) {
   const uint64_t n = hi - lo, W = (L + 31) / 32;
   bad.clear();
-  if (n == 0) return;
+  if (n == 0) return true;
   std::mutex bad_mu;
+  std::atomic<int> uneven{0};
   const uint64_t base = off ? off[lo] : 0;
   HostPool::instance().run_ranges(n, 8192, [&](uint64_t a, uint64_t b) {
     uint32_t local[64];
@@ -236,10 +237,17 @@ void pack_nt2_host(const uint8_t* ascii, const uint8_t* ascii_end, const uint64_
       bad.insert(bad.end(), local, local + nl);
       nl = 0;
     };
+    if (check_off) {  // the assumed length, checked against the batch's offsets (branch-free: vectorises)
+      uint64_t diff = 0;
+      const uint64_t* o = check_off + lo;
+      for (uint64_t q = a; q < b; q++) diff |= (o[q + 1] - o[q]) ^ L;
+      if (diff) { uneven.store(1, std::memory_order_relaxed); return; }
+    }
     if (!off && L <= 32) {  // k-mers: one load, one word per query
       const uint8_t* p = ascii + a * L;
       const int m = (int)L;
       for (uint64_t q = a; q < b; q++, p += L) {
+        _mm_prefetch(reinterpret_cast<const char*>(p + 1024), _MM_HINT_T0);
         bool ok = true;
         if (p + 32 <= ascii_end) _mm_stream_si64(reinterpret_cast<long long*>(words + q), (long long)pack32(p, m, &ok));  // written once, read by the DMA engine
         else ok = pack_query(p, L, ascii_end, words + q, 1);
@@ -256,6 +264,7 @@ void pack_nt2_host(const uint8_t* ascii, const uint8_t* ascii_end, const uint64_
     _mm_sfence();
   });
   if (bad.size() > 1) std::sort(bad.begin(), bad.end());
+  return uneven.load() == 0;
 }
 
 }  // namespace awry

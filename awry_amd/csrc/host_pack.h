@@ -40,8 +40,11 @@ class HostPool {
 // lens[q - lo].  ascii points at the first byte of query lo; ascii_end is the end of the readable buffer (32-byte loads
 // never cross it).  Queries holding a byte outside ACGTacgt are appended to `bad` (index relative to lo); their words
 // are unspecified.  Runs on the pool.
-void pack_nt2_host(const uint8_t* ascii, const uint8_t* ascii_end, const uint64_t* off, uint64_t lo, uint64_t hi, uint64_t L,
-                   uint64_t* words, uint32_t* lens, std::vector<uint32_t>& bad);
+// check_off (with off == nullptr): the caller only ASSUMES that every query has L letters; the packer reads the batch's
+// offsets as it goes and returns false as soon as check_off[q + 1] - check_off[q] != L for some q in [lo, hi) (the
+// output is then unspecified) -- this folds the length scan of a batch into the pass that reads its bytes anyway.
+bool pack_nt2_host(const uint8_t* ascii, const uint8_t* ascii_end, const uint64_t* off, uint64_t lo, uint64_t hi, uint64_t L,
+                   uint64_t* words, uint32_t* lens, std::vector<uint32_t>& bad, const uint64_t* check_off = nullptr);
 
 // memcpy cut over the pool (result-sized copies out of pinned staging)
 void pool_memcpy(void* dst, const void* src, size_t bytes);

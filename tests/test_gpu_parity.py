@@ -1112,3 +1112,30 @@ def test_non_canonical_text_letters(oracle, alphabet):
                 assert np.array_equal(np.sort(g[int(off[i]):int(off[i + 1])]), want_pos[i]), (dev, verify, qs[i])
             for q, c in list(zip(qs, want_count))[::37]:
                 assert ix.count_string(q) == c
+
+
+def test_assumed_uniform_length_is_checked(oracle):
+    """parallel_count assumes the first query's length for the whole batch and lets the host packer check the offsets as it
+    goes; a batch whose lengths differ but whose bytes add up to n x that length must fall back to the planned path"""
+    text, st, hd = synth.make_text(300000, 0, 17, 2, 0.02)
+    ix = gpu_index(text, 0, 8, 0, st, hd)
+    oi = oracle.OracleIndex.from_text(text, 0, 8, 0, st, hd)
+    n = 70001
+    lens = np.full(n, 24)
+    lens[1::2] = 23
+    lens[2::2] = 25  # first query 24 letters, then 23 / 25 alternating: n * 24 bytes in all
+    assert lens.sum() == n * 24
+    rng = np.random.default_rng(3)
+    qo = np.zeros(n + 1, dtype=np.uint64)
+    qo[1:] = np.cumsum(lens)
+    starts = rng.integers(0, len(text) - 40, size=n)
+    idx = np.repeat(starts, lens) + (np.arange(int(qo[-1])) - np.repeat(qo[:-1].astype(np.int64), lens))
+    qb = text[idx].copy()
+    qb[qb == ord("$")] = ord("A")
+    want, _ = oi.parallel_count(qb, qo, 4)
+    assert np.array_equal(ix.parallel_count_csr(qb, qo), want)
+    # and the common case itself: one length, above the threshold of the assumption
+    q2d = synth.sampled_queries(text, 80000, 24, 5)
+    qb, qo = synth.fixed_to_csr(q2d)
+    want, _ = oi.parallel_count(qb, qo, 4)
+    assert np.array_equal(ix.parallel_count_csr(qb, qo), want)

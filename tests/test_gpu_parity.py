@@ -1139,3 +1139,104 @@ def test_assumed_uniform_length_is_checked(oracle):
     qb, qo = synth.fixed_to_csr(q2d)
     want, _ = oi.parallel_count(qb, qo, 4)
     assert np.array_equal(ix.parallel_count_csr(qb, qo), want)
+
+
+def _check_located(text, st, q2d, positions, off, g, p, counts):
+    """size-independent properties of a locate result: count == number of locations, every located window holds its
+    query, every query drawn from the text finds its own position, (record, offset) = the largest record start <= position"""
+    L = q2d.shape[1]
+    assert np.array_equal(np.diff(off), counts) and len(g) == int(off[-1])
+    qi = np.repeat(np.arange(len(q2d)), counts.astype(np.int64))
+    assert np.array_equal(text[g.astype(np.int64)[:, None] + np.arange(L)[None, :]], q2d[qi])
+    for i in range(0, len(positions), 211):
+        assert positions[i] in g[int(off[i]):int(off[i + 1])]
+    if len(p):
+        starts = np.array(st, dtype=np.uint64)
+        si = np.searchsorted(starts, g, side="right") - 1
+        assert np.array_equal(p[:, 0], si.astype(np.uint64)) and np.array_equal(p[:, 1], g - starts[si])
+
+
+def test_grch38_scale_101bp_reads(oracle, tmp_path):
+    """BASELINE.json configs[2] at its own index size: 101-bp reads sampled from a GRCh38-scale text (3.1 Gbp, 25 records)
+    through awry_locate_batch and through the device-resident pipeline, with the accelerators (seed-and-verify, dense SA)
+    and without them (LF steps, walks to the file's samples); the oracle (same index via an .awry round trip) on a sample"""
+    n, recs, L = 3_100_000_000, 25, 101
+    text, st, hd = synth.make_text(n, 0, 0xA5A50000 + 2, recs, 0.05)
+    ix = gpu_index(text, 0, 8, 0, st, hd)
+    rng = np.random.default_rng(11)
+    pos = rng.integers(0, n - L, size=300_000)
+    win = text[pos[:, None] + np.arange(L)[None, :]]
+    ok = ~(win == ord("N")).any(axis=1)
+    pos, present = pos[ok][:200_000], win[ok][:200_000]
+    mutated = present[:20_000].copy()
+    mutated[np.arange(20_000), rng.integers(0, L, 20_000)] = synth.NT[rng.integers(0, 4, 20_000)]
+    q2d = np.concatenate([present, mutated, synth.random_queries(20_000, L, 0, 12)])
+    qb, qo = synth.fixed_to_csr(q2d)
+    path = str(tmp_path / "g.awry")
+    ix.save(path)
+    oi = oracle.OracleIndex.load(path)
+    ns = 20_000
+    sample = np.concatenate([np.arange(0, 200_000, 20)[:ns // 2], np.arange(200_000, 200_000 + ns // 2)])
+    sb, so = synth.fixed_to_csr(q2d[sample])
+    ooff, ogpos, opos, _ = oi.parallel_locate(sb, so, 8)
+    oi.close()
+    os.remove(path)
+    results = []
+    for accel in (True, False):
+        if not accel:
+            ix.set_verify(-1)
+            ix.set_locate_sa_ratio(0)
+        assert bool(ix.verify_enabled()) == accel
+        counts = ix.parallel_count_csr(qb, qo)
+        assert (counts[:len(present)] >= 1).all()
+        off, g, p = ix.parallel_locate_csr(qb, qo)                # the host boundary
+        _check_located(text, st, q2d, pos, off, g, p, counts)
+        off2, g2, p2 = ix.locate_reads_nt2(q2d)                   # packed words resident in HBM: count, scan, locate
+        assert np.array_equal(off2, off) and np.array_equal(g2, g) and np.array_equal(p2, p)
+        assert np.array_equal(np.diff(ooff), counts[sample])
+        assert np.array_equal(np.concatenate([g[int(off[i]):int(off[i + 1])] for i in sample]), ogpos)
+        assert np.array_equal(np.concatenate([p[int(off[i]):int(off[i + 1])] for i in sample]), opos)
+        results.append((off, g))
+    assert np.array_equal(results[0][0], results[1][0]) and np.array_equal(results[0][1], results[1][1])
+
+
+def test_swissprot_scale_amino_12mers(oracle, tmp_path):
+    """BASELINE.json configs[3] at its own size: 9e7 residues in 2.5e5 records, 12-mers through awry_count_batch (the amino
+    k-mer schedule), the device entry point and awry_locate_batch; properties on everything, the oracle on 1e5 queries"""
+    n, recs, L = 90_000_000, 250_000, 12
+    text, st, hd = synth.make_text(n, 1, 0xA5A50004, recs, 0.0)
+    ix = gpu_index(text, 1, 8, 0, st, hd)
+    rng = np.random.default_rng(12)
+    pos = rng.integers(0, n - L, size=200_000)
+    present = text[pos[:, None] + np.arange(L)[None, :]]     # windows that span a record boundary hold X: they search as X
+    q2d = np.concatenate([present, synth.random_queries(200_000, L, 1, 13)])
+    qb, qo = synth.fixed_to_csr(q2d)
+    counts = ix.parallel_count_csr(qb, qo)
+    assert (counts[:len(present)] >= 1).all()
+    d_q, d_c = ix.dev_upload(np.concatenate([qb, np.zeros(16, np.uint8)])), ix.dev_malloc(8 * len(q2d))
+    ix.dev_count_ascii_uniform(d_q, len(q2d), L, d_c)
+    ix.dev_synchronize()
+    assert np.array_equal(ix.dev_download(d_c, (len(q2d),), np.uint64), counts)
+    ix.dev_free(d_q)
+    ix.dev_free(d_c)
+    off, g, p = ix.parallel_locate_csr(qb, qo)
+    _check_located(text, st, q2d, pos, off, g, p, counts)
+    path = str(tmp_path / "a.awry")
+    ix.save(path)
+    oi = oracle.OracleIndex.load(path)
+    sample = np.sort(rng.choice(len(q2d), size=100_000, replace=False))
+    sb, so = synth.fixed_to_csr(q2d[sample])
+    ooff, ogpos, opos, _ = oi.parallel_locate(sb, so, 8)
+    oi.close()
+    assert np.array_equal(np.diff(ooff), counts[sample])
+    assert np.array_equal(np.concatenate([g[int(off[i]):int(off[i + 1])] for i in sample]), ogpos)
+    assert np.array_equal(np.concatenate([p[int(off[i]):int(off[i + 1])] for i in sample]), opos)
+    # unequal lengths (8..24 residues): no k-mer schedule for these, the generic pipeline must agree with the oracle too
+    lens = rng.integers(8, 25, size=50_000)
+    ro = np.zeros(len(lens) + 1, dtype=np.uint64)
+    ro[1:] = np.cumsum(lens)
+    starts = rng.integers(0, n - 30, size=len(lens))
+    idx = np.repeat(starts, lens) + (np.arange(int(ro[-1])) - np.repeat(ro[:-1].astype(np.int64), lens))
+    rb = text[idx].copy()
+    want, _ = oracle.OracleIndex.load(path).parallel_count(rb, ro, 8)
+    assert np.array_equal(ix.parallel_count_csr(rb, ro), want)

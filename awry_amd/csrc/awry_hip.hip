@@ -383,7 +383,7 @@ void sync_seed_mode(awry_index* ix, Replica& r) {
   // context letters beyond the 14 of the count field ride in the top bits of sp that positions of this text never use
   const int extra = nt ? (int)std::min<uint64_t>(15, (32 - std::min<uint64_t>(32, h.sa_bits)) / 2) : 0;
   hipLaunchKernelGGL(seed_rows_to_positions_kernel, dim3(grid_for(r, nfinal, 256)), dim3(256), 0, r.stream, r.seed.p, nfinal, r.dense_sa.p,
-                     nt ? SEED_CNT_SAT : AA_SEED_CNT_SAT, nt ? r.dev.text4 : nullptr, extra);
+                     nt ? SEED_CNT_SAT : AA_SEED_CNT_SAT, nt ? r.dev.text4 : nullptr, extra, nt ? nullptr : r.dev.text8);
   r.dev.ctx_extra = (uint32_t)extra;
   HIP_CHECK(hipGetLastError());
   HIP_CHECK(hipStreamSynchronize(r.stream));
@@ -876,13 +876,16 @@ void launch_count_ascii_uniform(Replica& r, const uint8_t* d_q, uint64_t n, uint
     sc->cap = 0;  // the nucleotide k-mer path re-allocates its three lists together
   }
   if (!sc->count.p) sc->count.alloc(nblk);
-  const QueryList ql{sc->q.p, sc->count.p, per_block, nullptr, nullptr, 0, d_tally};
+  // the second pass works through all lists as one pool on a grid sized to what is resident at once (3 blocks per CU)
+  const bool pooled = nblk <= (unsigned)LIST_MAX_LISTS && !getenv("AWRY_AA_LIST_PER_BLOCK");
+  const QueryList ql{sc->q.p, sc->count.p, per_block, nullptr, nullptr, 0, d_tally, pooled ? nblk : 0u};
+  const unsigned nblk2 = pooled ? (unsigned)r.num_cus * 3 : nblk;
   // Two queries in flight per lane (one: the same rate; four: 141 VGPRs, 10 % slower).  The second pass is a latency
   // chain over a few per cent of the batch; running it for the first half of a batch on a side stream beside the first
   // pass of the second half (event fork / join) was measured and costs more than it hides (12.7 -> 10.7 G present
   // 12-mers/s, host path 0.83 -> 0.52 G queries/s).
   hipLaunchKernelGGL(count_aa_kmer_probe_kernel<2>, dim3(nblk), dim3(256), 0, s, r.dev, d_q, n, (int)L, d_counts, d_ranges, d_status, ql);
-  hipLaunchKernelGGL((count_scalar_kernel<AMINO, LIST_BLOCK>), dim3(nblk), dim3(256), 0, s, r.dev, d_q, nullptr, n, d_counts, d_ranges, d_status, 1, L, ql);
+  hipLaunchKernelGGL((count_scalar_kernel<AMINO, LIST_BLOCK>), dim3(nblk2), dim3(256), 0, s, r.dev, d_q, nullptr, n, d_counts, d_ranges, d_status, 1, L, ql);
   HIP_CHECK(hipGetLastError());
 }
 

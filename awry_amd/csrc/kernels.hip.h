@@ -206,10 +206,16 @@ struct QueryList {
                                     //   the packed read kernels' range_start), otherwise (start, end) pairs
   unsigned long long* tally;        // nullable work census (untimed runs): [0] seed probes, [1] executed steps, [2] distinct
                                     //   blocks ranked, [3] SA reads and [4] text comparisons of seed-and-verify
+  uint32_t nlists;                  // LIST_BLOCK: number of per-block lists (the first pass's grid), <= LIST_MAX_LISTS: the
+                                    //   lists are then worked through as ONE pool by whatever grid this pass is launched
+                                    //   with (0: block b takes list b)
 };
+constexpr int LIST_MAX_LISTS = 4096;
 __device__ __forceinline__ void tally_add(unsigned long long* tally, int slot, unsigned long long v) {
   if (tally && v) atomicAdd(&tally[slot], v);
 }
+
+__device__ __forceinline__ uint64_t block_excl_scan(uint64_t v, uint64_t* tot);
 
 template <int A, int LIST = LIST_NONE>
 __global__ __launch_bounds__(256) void count_scalar_kernel(DevIndex ix, const uint8_t* __restrict__ ascii,
@@ -217,13 +223,39 @@ __global__ __launch_bounds__(256) void count_scalar_kernel(DevIndex ix, const ui
                                                            uint64_t* __restrict__ counts, uint64_t* __restrict__ ranges,
                                                            uint8_t* __restrict__ status, int allow_verify, uint64_t ulen, QueryList ql) {
   __shared__ uint8_t lut[256];
+  // LIST_BLOCK with ql.nlists: exclusive prefix sums of the lists' lengths.  The kernel holds ~140 VGPRs (3 waves per
+  // SIMD), so a grid of one block per list ran in three rounds, each as long as the longest chain of dependent loads in
+  // it -- 66 us for a few hundred thousand queries; as one pool the listed queries spread over every resident thread.
+  __shared__ uint32_t s_pref[LIST == LIST_BLOCK ? LIST_MAX_LISTS + 1 : 1];
   lut[threadIdx.x] = (uint8_t)(threadIdx.x >= 128 ? 0xFF : index_of_ascii(A, (uint8_t)threadIdx.x));
+  const bool pooled = LIST == LIST_BLOCK && ql.nlists != 0;
+  uint64_t pool_total = 0;
+  if (LIST == LIST_BLOCK && pooled) {
+    const uint32_t per = (ql.nlists + blockDim.x - 1) / blockDim.x;  // consecutive lists per thread
+    const uint32_t l0 = threadIdx.x * per;
+    uint64_t mine = 0;
+    for (uint32_t j = 0; j < per; j++) mine += l0 + j < ql.nlists ? ql.count[l0 + j] : 0u;
+    uint64_t tot;
+    uint64_t run = block_excl_scan(mine, &tot);
+    for (uint32_t j = 0; j < per; j++)
+      if (l0 + j < ql.nlists) { s_pref[l0 + j] = (uint32_t)run; run += ql.count[l0 + j]; }
+    if (threadIdx.x == 0) s_pref[ql.nlists] = (uint32_t)tot;
+    pool_total = tot;
+  }
   __syncthreads();
-  const uint64_t stride = LIST == LIST_BLOCK ? blockDim.x : (uint64_t)gridDim.x * blockDim.x;
-  const uint64_t todo = LIST == LIST_BLOCK ? ql.count[blockIdx.x] : (LIST == LIST_GLOBAL ? (uint64_t)*ql.total : (LIST == LIST_COMPACT ? ql.cap : n));
+  const uint64_t stride = LIST == LIST_BLOCK && !pooled ? blockDim.x : (uint64_t)gridDim.x * blockDim.x;
+  const uint64_t todo = LIST == LIST_BLOCK ? (pooled ? pool_total : (uint64_t)ql.count[blockIdx.x])
+                                           : (LIST == LIST_GLOBAL ? (uint64_t)*ql.total : (LIST == LIST_COMPACT ? ql.cap : n));
   const uint8_t* const ascii_bytes = ascii;
-  for (uint64_t it = LIST == LIST_BLOCK ? threadIdx.x : (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; it < todo; it += stride) {
-    const uint64_t q = LIST == LIST_BLOCK ? ql.q[(uint64_t)blockIdx.x * ql.cap + it] : (LIST == LIST_GLOBAL || LIST == LIST_COMPACT ? ql.q[it] : it);
+  for (uint64_t it = LIST == LIST_BLOCK && !pooled ? threadIdx.x : (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; it < todo; it += stride) {
+    uint64_t q;
+    if (LIST == LIST_BLOCK && pooled) {  // item `it` of the pool: list l with s_pref[l] <= it < s_pref[l + 1]
+      uint32_t lo = 0, hi = ql.nlists;
+      while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (s_pref[mid] <= (uint32_t)it) lo = mid; else hi = mid; }
+      q = ql.q[(uint64_t)lo * ql.cap + (it - s_pref[lo])];
+    } else {
+      q = LIST == LIST_BLOCK ? ql.q[(uint64_t)blockIdx.x * ql.cap + it] : (LIST == LIST_GLOBAL || LIST == LIST_COMPACT ? ql.q[it] : it);
+    }
     const uint64_t b = LIST == LIST_COMPACT ? off[it] : (ulen ? q * ulen : off[q]);
     const uint64_t e = LIST == LIST_COMPACT ? off[it + 1] : (ulen ? b + ulen : off[q + 1]);
     ByteStream ascii(ascii_bytes);  // shadows the pointer: same indexing, 8 bytes per load
@@ -265,8 +297,10 @@ __global__ __launch_bounds__(256) void count_scalar_kernel(DevIndex ix, const ui
         if (std20) {
           const SeedEntry se = ix.seed[sidx];
           tally_add(ql.tally, 0, 1);
-          const uint32_t scnt = se.cnt & AA_SEED_CNT_SAT;
-          const bool wrong_sym = scnt == 1 && e - k > b && (int)(se.cnt >> 27) != (int)lut[ascii[e - k - 1]];  // BWT[row] is not the next residue
+          const uint32_t scnt = aa_seed_cnt(se);
+          // BWT[row] is not the next residue / the next residue does not occur in the BWT over the entry's 2..4 rows
+          const bool wrong_sym = e - k > b && ((scnt == 1 && (int)aa_seed_sym(se) != (int)lut[ascii[e - k - 1]]) ||
+                                               (aa_seed_is_multi(se) && !((aa_seed_mask(se) >> lut[ascii[e - k - 1]]) & 1u)));
           if (ix.seed_pos && scnt == 1 && !wrong_sym) {  // position seed, as in the nucleotide branch below
             const uint64_t rem = e - k - b, p = se.sp;
             if (allow_verify && ix.text8 && rem < 65536) {
@@ -333,7 +367,9 @@ __global__ __launch_bounds__(256) void count_scalar_kernel(DevIndex ix, const ui
       const bool can_verify = allow_verify && ix.text8 && ix.dense_sa && ix.dense_ratio == 1;
       while (i > b && sp <= ep) {        // emptiness is sticky, so stopping early never changes the count
         const uint64_t rem = i - b, cnt = ep - sp + 1;
-        if (can_verify && cnt <= 4 && 3 * cnt <= rem && rem < 65536) {
+        // (second pass of the amino k-mer schedule: what counts there is the length of the chain of dependent loads, and
+        //  SA + text is two of them where every LF step is one more)
+        if (can_verify && cnt <= 4 && (3 * cnt <= rem || LIST == LIST_BLOCK) && rem < 65536) {
           uint32_t mask = 0;
           uint64_t g1 = 0;
           for (uint64_t c = 0; c < cnt; c++) {
@@ -382,6 +418,11 @@ __global__ __launch_bounds__(256) void count_scalar_kernel(DevIndex ix, const ui
 // ranges (optional): what the locate pass reads for a settled query, in the generic kernel's layout -- ranges[2q] = a row
 // interval's start or an RS_SINGLE / RS_MULTI word (verified text position / candidate rows + mask), ranges[2q + 1] = 0.
 constexpr int AA_KMER_MIN = 8, AA_KMER_MAX = 24;
+// symbol index of residue j of a query held as three words of one index per byte
+__device__ __forceinline__ uint32_t jn_idx(uint64_t i0, uint64_t i1, uint64_t i2, int j) {
+  const uint64_t w = j < 8 ? i0 : (j < 16 ? i1 : i2);
+  return (uint32_t)((w >> (8 * (j & 7))) & 0xFF);
+}
 constexpr int AA_KMER_VMULTI = 4;        // seed ranges of up to this many rows are verified candidate by candidate
 constexpr int AA_KMER_VMULTI_LANES = 8;  //   when at least this many lanes of the wave hold one
 
@@ -479,7 +520,7 @@ __global__ __launch_bounds__(256) void count_aa_kmer_probe_kernel(DevIndex ix, c
 #pragma unroll
     for (int h = 0; h < NQ; h++) {
       const SeedEntry e = ev[h];
-      const uint32_t scnt = e.cnt & AA_SEED_CNT_SAT;
+      const uint32_t scnt = aa_seed_cnt(e);
       listed[h] = vfy[h] = multi[h] = false;
       value[h] = 0;
       rs[h] = (RS_PLAIN << RS_MODE_SHIFT) | 1ull;  // no hits
@@ -494,7 +535,16 @@ __global__ __launch_bounds__(256) void count_aa_kmer_probe_kernel(DevIndex ix, c
       else if (scnt == 1u) {
         const int jn = rem - 1;  // the residue in front of the seed window must be BWT[row]
         const uint64_t wn = jn < 8 ? i0[h] : (jn < 16 ? i1[h] : i2[h]);
-        if ((uint32_t)((wn >> (8 * (jn & 7))) & 0xFF) != (e.cnt >> 27)) value[h] = 0;
+        if ((uint32_t)((wn >> (8 * (jn & 7))) & 0xFF) != aa_seed_sym(e)) value[h] = 0;
+        else if (aa_seed_is_ctx(e) && rem <= AA_SEED_CTX_LEN) {
+          // the entry holds the residues in front of the one occurrence: decided here, no text access
+          uint32_t qctx = 0;  // query residues rem-2, rem-3, ... 0 in the entry's order (rem <= 6: all in bytes 0..7)
+#pragma unroll
+          for (int j = 0; j < AA_SEED_CTX_LEN - 1; j++)
+            if (j < rem - 1) qctx |= (uint32_t)((i0[h] >> (8 * (rem - 2 - j))) & 0x1Fu) << (5 * j);
+          const uint32_t cmask = rem >= 2 ? (1u << (5 * (rem - 1))) - 1u : 0u;
+          if ((aa_seed_ctx(e) & cmask) == qctx) { value[h] = 1; rs[h] = (RS_SINGLE << RS_MODE_SHIFT) | ((uint64_t)e.sp - (uint64_t)rem); }
+        }
         else if (pos) {
           if (e.sp >= (uint32_t)rem) {  // else the suffix starts too close to the text's beginning
             vfy[h] = true;  // the window's loads are issued here, for all NQ queries, and compared below
@@ -504,6 +554,8 @@ __global__ __launch_bounds__(256) void count_aa_kmer_probe_kernel(DevIndex ix, c
             if (rem > 16) t2[h] = ld8(t + 16);
           }
         } else listed[h] = true;
+      } else if (aa_seed_is_multi(e) && !((aa_seed_mask(e) >> ((jn_idx(i0[h], i1[h], i2[h], rem - 1)) & 0x1Fu)) & 1u)) {
+        value[h] = 0;  // the residue in front of the seed window does not occur in the BWT over the entry's rows: absent
       } else if (pos && scnt <= (uint32_t)AA_KMER_VMULTI) multi[h] = true;
       else listed[h] = true;
     }
@@ -522,7 +574,7 @@ __global__ __launch_bounds__(256) void count_aa_kmer_probe_kernel(DevIndex ix, c
       const uint64_t mm = __ballot(multi[h]);
       if (__popcll(mm) < AA_KMER_VMULTI_LANES) { listed[h] = listed[h] || multi[h]; multi[h] = false; }
       if (multi[h]) {
-        const uint32_t sp = ev[h].sp, nc = ev[h].cnt & AA_SEED_CNT_SAT;
+        const uint32_t sp = ev[h].sp, nc = aa_seed_cnt(ev[h]);
         uint32_t p[AA_KMER_VMULTI];
 #pragma unroll
         for (int c = 0; c < AA_KMER_VMULTI; c++) p[c] = (uint32_t)c < nc ? ix.dense_sa[sp + c] : 0u;
@@ -1437,9 +1489,11 @@ __global__ __launch_bounds__(256) void seed_finalize_kernel(DevIndex ix, SeedEnt
 // single candidate is, and the text decides (2 random lines per such query instead of 3).
 // text4 != nullptr (nucleotide): where the SEED_CTX_LEN + extra letters in front of the occurrence exist and are all
 // ACGT they go into the entry as well (SEED_CTX, layout.h).
+// text8 != nullptr (amino): where the five residues in front of BWT[row]'s exist they go into the entry (AA_SEED_SPECIAL).
 __global__ __launch_bounds__(256) void seed_rows_to_positions_kernel(SeedEntry* __restrict__ table, uint64_t nentries,
                                                                      const uint32_t* __restrict__ dense_sa, uint32_t cnt_mask,
-                                                                     const uint32_t* __restrict__ text4, int extra) {
+                                                                     const uint32_t* __restrict__ text4, int extra,
+                                                                     const uint8_t* __restrict__ text8 = nullptr) {
   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
   const int clen = SEED_CTX_LEN + extra;  // <= 30
   auto letters16 = [](uint64_t x) {  // 16 nibbles -> 16 2-bit letters
@@ -1451,7 +1505,19 @@ __global__ __launch_bounds__(256) void seed_rows_to_positions_kernel(SeedEntry* 
   };
   for (uint64_t o = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; o < nentries; o += stride) {
     SeedEntry e = table[o];
-    if ((e.cnt & cnt_mask) != 1u) continue;  // cnt_mask: SEED_CNT_SAT (nt) / AA_SEED_CNT_SAT (aa)
+    if (text8) {  // amino entry: plain singletons only (bit 26 clear, count 1)
+      if ((e.cnt & (AA_SEED_SPECIAL | AA_SEED_CNT_SAT)) != 1u) continue;
+      const uint32_t p = dense_sa[e.sp];
+      e.sp = p;
+      if (p >= (uint32_t)AA_SEED_CTX_LEN) {  // text8[p - 1] is the BWT symbol already held in bits 27..31
+        uint32_t ctx = 0;
+        for (int j = 0; j < AA_SEED_CTX_LEN - 1; j++) ctx |= (uint32_t)(text8[p - 2 - j] & 0x1Fu) << (5 * j);
+        e.cnt = (e.cnt & 0xF8000000u) | AA_SEED_SPECIAL | ctx;
+      }
+      table[o] = e;
+      continue;
+    }
+    if ((e.cnt & cnt_mask) != 1u) continue;  // cnt_mask: SEED_CNT_SAT (nt)
     const uint32_t p = dense_sa[e.sp];
     e.sp = p;
     if (text4 && p >= (uint32_t)clen) {
@@ -1507,6 +1573,11 @@ __global__ __launch_bounds__(256) void aa_seed_finalize_kernel(DevIndex ix, Seed
   for (uint64_t o = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; o < nentries; o += stride) {
     SeedEntry e = table[o];
     if (e.cnt == 1u) e.cnt = 1u | ((uint32_t)symbol_at<AMINO>(ix, e.sp) << 27);
+    else if (e.cnt >= 2u && e.cnt <= 4u) {  // the set of BWT symbols over the entry's rows (AA_SEED_MULTI, layout.h)
+      uint32_t mask = 0;
+      for (uint32_t j = 0; j < e.cnt; j++) mask |= 1u << symbol_at<AMINO>(ix, (uint64_t)e.sp + j);
+      e.cnt = AA_SEED_SPECIAL | AA_SEED_MULTI | ((e.cnt - 2u) << 22) | mask;
+    }
     else if (e.cnt >= AA_SEED_CNT_SAT) e.cnt = AA_SEED_CNT_SAT;
     else continue;
     table[o] = e;

@@ -89,8 +89,27 @@ AWRY_HD uint64_t seed_full_ctx(SeedEntry e, int extra) {
 }
 AWRY_HD int seed_sym(SeedEntry e) { return (int)(e.cnt >> 29); }
 
-// amino seed entries: count in bits 0..26 (saturating), 5-bit symbol index of a singleton's BWT row in bits 27..31
-constexpr uint32_t AA_SEED_CNT_SAT = 0x07FFFFFFu;
+// Amino seed entries (final level).  Plain: count in bits 0..25 (saturating at AA_SEED_CNT_SAT = "at least this many:
+// ignore the table"), and for singletons the 5-bit symbol index of BWT[sp] -- the residue in front of the one occurrence
+// -- in bits 27..31.  Bit 26 (AA_SEED_SPECIAL) marks the two encodings that let the ENTRY decide most k-mer queries:
+//   * bit 25 clear: a singleton whose sp is the text position p of its occurrence (position seeds) and whose bits 0..24
+//     hold five more residues in front of it, text[p - 2 - j] in bits [5j, 5j + 5) -- with the BWT symbol that is the
+//     AA_SEED_CTX_LEN = 6 residues left of the seed window: a 12-mer probed with k = 7 needs no text access;
+//   * bit 25 set (AA_SEED_MULTI): a range of 2..4 rows, sp its first row, count - 2 in bits 22..23, and in bits 0..21
+//     the set of symbol indices that occur in the BWT over those rows: a query whose next residue is not among them
+//     is absent (most random queries that hit such an entry).
+constexpr uint32_t AA_SEED_CNT_SAT = 0x03FFFFFFu;
+constexpr uint32_t AA_SEED_SPECIAL = 0x04000000u;
+constexpr uint32_t AA_SEED_MULTI = 0x02000000u;
+constexpr int AA_SEED_CTX_LEN = 6;
+AWRY_HD bool aa_seed_is_ctx(SeedEntry e) { return (e.cnt & (AA_SEED_SPECIAL | AA_SEED_MULTI)) == AA_SEED_SPECIAL; }
+AWRY_HD bool aa_seed_is_multi(SeedEntry e) { return (e.cnt & (AA_SEED_SPECIAL | AA_SEED_MULTI)) == (AA_SEED_SPECIAL | AA_SEED_MULTI); }
+AWRY_HD uint32_t aa_seed_cnt(SeedEntry e) {
+  return (e.cnt & AA_SEED_SPECIAL) ? ((e.cnt & AA_SEED_MULTI) ? ((e.cnt >> 22) & 3u) + 2u : 1u) : (e.cnt & AA_SEED_CNT_SAT);
+}
+AWRY_HD uint32_t aa_seed_sym(SeedEntry e) { return e.cnt >> 27; }        // singletons (plain or with context)
+AWRY_HD uint32_t aa_seed_mask(SeedEntry e) { return e.cnt & 0x3FFFFFu; }  // AA_SEED_MULTI entries
+AWRY_HD uint32_t aa_seed_ctx(SeedEntry e) { return e.cnt & 0x1FFFFFFu; }  // context entries: residues p-2 .. p-6
 AWRY_HD int aa_index_of_letter(int l) { return l < 19 ? l + 1 : 21; }  // the 20 standard residues: 0..18 -> A..W, 19 -> Y
 AWRY_HD int aa_letter_of_index(int idx) { return idx >= 1 && idx <= 19 ? idx - 1 : (idx == 21 ? 19 : -1); }
 

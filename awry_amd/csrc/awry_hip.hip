@@ -304,7 +304,7 @@ int default_seed_k(const HostIndex& h) {
     k = std::max(1, std::min(k, 7));
     size_t free_b = 0;
     if (hbm_budget(&free_b))
-      while (k > 1 && 8.5 * std::pow(20.0, k) > 0.7 * (double)free_b) k--;
+      while (k > 1 && 8.5 * std::pow((double)AA_SEED_SIGMA, k) > 0.7 * (double)free_b) k--;
     return k;
   }
   // Several table entries per suffix: k = floor(log4 bwt_len) + 2, i.e. 4^k = 4..16 x bwt_len (GRCh38: k = 17, 137 GB of
@@ -330,7 +330,7 @@ void build_seed(awry_index* ix, Replica& r, int k) {
   if (k <= 0) return;
   require(narrow(ix->host), "seed table needs an index with bwt_len < 2^32");
   const bool nt = ix->host.alphabet == NUCLEOTIDE;
-  const uint64_t sigma = nt ? 4 : 20;
+  const uint64_t sigma = nt ? 4 : AA_SEED_SIGMA;
   require(k <= (nt ? 17 : 7), "seed k-mer length must be <= 17 (nucleotide) / 7 (amino)");
   uint64_t nfinal = 1;
   for (int j = 0; j < k; j++) nfinal *= sigma;
@@ -379,7 +379,7 @@ void sync_seed_mode(awry_index* ix, Replica& r) {
     return;
   }
   uint64_t nfinal = 1;
-  for (int j = 0; j < r.seed_k; j++) nfinal *= nt ? 4 : 20;
+  for (int j = 0; j < r.seed_k; j++) nfinal *= nt ? 4 : AA_SEED_SIGMA;
   // context letters beyond the 14 of the count field ride in the top bits of sp that positions of this text never use
   const int extra = nt ? (int)std::min<uint64_t>(15, (32 - std::min<uint64_t>(32, h.sa_bits)) / 2) : 0;
   hipLaunchKernelGGL(seed_rows_to_positions_kernel, dim3(grid_for(r, nfinal, 256)), dim3(256), 0, r.stream, r.seed.p, nfinal, r.dense_sa.p,

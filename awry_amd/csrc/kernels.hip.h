@@ -292,7 +292,7 @@ __global__ __launch_bounds__(256) void count_scalar_kernel(DevIndex ix, const ui
         for (int j = k - 1; j >= 0; j--) {  // leftmost window letter least significant
           const int letter = aa_letter_of_index(lut[ascii[e - k + j]]);
           std20 = std20 && letter >= 0;
-          sidx = sidx * 20 + (uint64_t)(letter < 0 ? 0 : letter);
+          sidx = sidx * AA_SEED_SIGMA + (uint64_t)(letter < 0 ? 0 : letter);
         }
         if (std20) {
           const SeedEntry se = ix.seed[sidx];
@@ -372,6 +372,37 @@ __global__ __launch_bounds__(256) void count_scalar_kernel(DevIndex ix, const ui
         if (can_verify && cnt <= 4 && (3 * cnt <= rem || LIST == LIST_BLOCK) && rem < 65536) {
           uint32_t mask = 0;
           uint64_t g1 = 0;
+          if (A == AMINO && rem <= 24) {
+            // short rests (k-mers): the candidates' SA entries, then their text words, are fetched TOGETHER -- two or three
+            // dependent round trips for up to four candidates instead of two or three per candidate
+            uint32_t pc[4];
+#pragma unroll
+            for (int c = 0; c < 4; c++) pc[c] = (uint64_t)c < cnt ? ix.dense_sa[sp + c] : 0u;
+            uint64_t diff[4] = {0, 0, 0, 0};
+            for (uint64_t w0 = 0; w0 < rem; w0 += 8) {
+              const int nb = rem - w0 < 8 ? (int)(rem - w0) : 8;
+              uint64_t qw = 0;
+              for (int t = 0; t < nb; t++) qw |= (uint64_t)lut[ascii[b + w0 + t]] << (8 * t);
+              const uint64_t m = nb >= 8 ? ~0ull : (1ull << (8 * nb)) - 1;
+              uint64_t tw[4];
+#pragma unroll
+              for (int c = 0; c < 4; c++) {
+                tw[c] = ~qw;
+                if ((uint64_t)c < cnt && pc[c] >= rem) __builtin_memcpy(&tw[c], ix.text8 + ((uint64_t)pc[c] - rem) + w0, 8);  // (16 bytes of slack behind the text)
+              }
+#pragma unroll
+              for (int c = 0; c < 4; c++) diff[c] |= (tw[c] ^ qw) & m;
+            }
+#pragma unroll
+            for (int c = 0; c < 4; c++)
+              if ((uint64_t)c < cnt) {
+                tally_add(ql.tally, 3, 1);
+                if (pc[c] >= rem) {
+                  tally_add(ql.tally, 4, 1);
+                  if (!diff[c]) { mask |= 1u << c; g1 = (uint64_t)pc[c] - rem; }
+                }
+              }
+          } else
           for (uint64_t c = 0; c < cnt; c++) {
             const uint64_t p = ix.dense_sa[sp + c];
             tally_add(ql.tally, 3, 1);
@@ -488,7 +519,7 @@ __global__ __launch_bounds__(256) void count_aa_kmer_probe_kernel(DevIndex ix, c
     SeedEntry ev[NQ];
 #pragma unroll
     for (int h = 0; h < NQ; h++) {
-      uint32_t slot = 0, mul = 1, fl = 0;  // 20^7 < 2^32
+      uint32_t slot = 0, mul = 1, fl = 0;  // 21^7 < 2^32
       auto word = [&](uint64_t c, int base) {
         uint64_t iw = 0;
 #pragma unroll
@@ -501,7 +532,7 @@ __global__ __launch_bounds__(256) void count_aa_kmer_probe_kernel(DevIndex ix, c
             if (j >= rem) {  // seed window: leftmost residue least significant
               fl |= t & 0x4000u;
               slot += ((t >> 8) & 0x1Fu) * mul;
-              mul *= 20u;
+              mul *= (uint32_t)AA_SEED_SIGMA;
             }
           }
         }
@@ -1540,12 +1571,12 @@ __global__ __launch_bounds__(256) void seed_rows_to_positions_kernel(SeedEntry* 
   }
 }
 
-// Amino seed table (20 standard residues; X and '$' are never part of a window).  Same construction as the
-// nucleotide table with sigma = 20: entry o of level j+1 = one step of parent o / 20 with letter o % 20 (the
+// Amino seed table (the 21 searchable symbols: 20 standard residues and X; '$' is never part of a window).  Same construction as the
+// nucleotide table with sigma = 21 (layout.h, AA_SEED_SIGMA): entry o of level j+1 = one step of parent o / 21 with letter o % 21 (the
 // leftmost window letter is the least significant digit).  Final entries pack the count in bits 0..26 (saturating
 // at AA_SEED_CNT_SAT) and, for singletons, the 5-bit symbol index of BWT[sp] in bits 27..31.
 __global__ __launch_bounds__(256) void aa_seed_level1_kernel(DevIndex ix, SeedEntry* __restrict__ out) {
-  if (blockIdx.x == 0 && threadIdx.x < 20) {
+  if (blockIdx.x == 0 && threadIdx.x < AA_SEED_SIGMA) {
     const int idx = aa_index_of_letter((int)threadIdx.x);
     const uint64_t s = ix.prefix_sums[idx], e = ix.prefix_sums[idx + 1];
     out[threadIdx.x] = SeedEntry{(uint32_t)s, (uint32_t)(e - s)};
@@ -1556,11 +1587,11 @@ __global__ __launch_bounds__(256) void aa_seed_extend_kernel(DevIndex ix, const 
                                                              SeedEntry* __restrict__ child, uint64_t nchild) {
   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
   for (uint64_t o = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; o < nchild; o += stride) {
-    const SeedEntry p = parent[o / 20];
+    const SeedEntry p = parent[o / AA_SEED_SIGMA];
     SeedEntry r{p.sp, 0};
     if (p.cnt) {
       uint64_t sp = p.sp, ep = (uint64_t)p.sp + p.cnt - 1;
-      step_scalar<AMINO>(ix, sp, ep, aa_index_of_letter((int)(o % 20)));
+      step_scalar<AMINO>(ix, sp, ep, aa_index_of_letter((int)(o % AA_SEED_SIGMA)));
       r.sp = (uint32_t)sp;
       r.cnt = sp > ep ? 0u : (uint32_t)(ep - sp + 1);
     }

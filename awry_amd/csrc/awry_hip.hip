@@ -470,11 +470,50 @@ void launch_pack_nt2(Replica& r, const uint8_t* d_ascii, const uint64_t* d_off, 
   HIP_CHECK(hipGetLastError());
 }
 
+Replica::SurvScratch* surv_scratch(Replica& r, hipStream_t s);
+
+// The amino k-mer schedule: count_aa_kmer_probe_kernel (one query per lane: the seed entry, or the entry plus a text
+// window, decides most) and the generic kernel over what it listed, as one pool.  d_off == nullptr: n queries of L residues
+// back to back; else query q = d_q[d_off[q], d_off[q + 1]) of any length (k .. 24 residues take the first pass, the rest
+// is listed).  d_ranges (optional): RS_* words / row starts for the locate pass, in the generic kernel's layout.
+void launch_aa_two_phase(Replica& r, const uint8_t* d_q, const uint64_t* d_off, uint64_t n, int L, uint64_t* d_counts, uint64_t* d_ranges,
+                         uint8_t* d_status, hipStream_t s, unsigned long long* d_tally) {
+  Replica::SurvScratch* sc = surv_scratch(r, s);
+  const unsigned nblk = (unsigned)r.num_cus * 8;
+  const uint64_t per_block = ((n + (uint64_t)nblk * 256 - 1) / ((uint64_t)nblk * 256)) * 256;  // queries a block sees
+  if (sc->cap_q < per_block * nblk) {
+    HIP_CHECK(hipStreamSynchronize(s));
+    sc->q.alloc(per_block * nblk);
+    sc->cap_q = per_block * nblk;
+    sc->cap = 0;  // the nucleotide k-mer path re-allocates its three lists together
+  }
+  if (!sc->count.p) sc->count.alloc(nblk);
+  // the second pass works through all lists as one pool on a grid sized to what is resident at once (3 blocks per CU)
+  const bool pooled = nblk <= (unsigned)LIST_MAX_LISTS && !getenv("AWRY_AA_LIST_PER_BLOCK");
+  const QueryList ql{sc->q.p, sc->count.p, per_block, nullptr, nullptr, 0, d_tally, pooled ? nblk : 0u};
+  const unsigned nblk2 = pooled ? (unsigned)r.num_cus * 3 : nblk;
+  // Two queries in flight per lane (one: the same rate; four: 141 VGPRs, 10 % slower).  The second pass is a latency
+  // chain over a few per cent of the batch; running it for the first half of a batch on a side stream beside the first
+  // pass of the second half (event fork / join) was measured and costs more than it hides (12.7 -> 10.7 G present
+  // 12-mers/s, host path 0.83 -> 0.52 G queries/s).
+  if (d_off) hipLaunchKernelGGL((count_aa_kmer_probe_kernel<2, true>), dim3(nblk), dim3(256), 0, s, r.dev, d_q, d_off, n, 0, d_counts, d_ranges, d_status, ql);
+  else hipLaunchKernelGGL((count_aa_kmer_probe_kernel<2, false>), dim3(nblk), dim3(256), 0, s, r.dev, d_q, d_off, n, L, d_counts, d_ranges, d_status, ql);
+  hipLaunchKernelGGL((count_scalar_kernel<AMINO, LIST_BLOCK>), dim3(nblk2), dim3(256), 0, s, r.dev, d_q, d_off, n, d_counts, d_ranges, d_status, 1,
+                     d_off ? 0 : (uint64_t)L, ql);
+  HIP_CHECK(hipGetLastError());
+}
+
 // allow_verify: the generic kernel may finish queries against the text (ranges then hold RS_* words for locate, not rows)
 // ulen != 0: n queries of ulen bytes each, back to back (d_off is not read)
 void launch_count_ascii(Replica& r, const uint8_t* d_q, const uint64_t* d_off, uint64_t n, uint64_t* d_counts,
                         uint64_t* d_ranges, uint8_t* d_status, hipStream_t s, bool allow_verify, uint64_t ulen = 0) {
   if (n == 0) return;
+  static const bool aa_off = getenv("AWRY_AA_KMER") && !strcmp(getenv("AWRY_AA_KMER"), "0");
+  if (r.dev.alphabet == AMINO && allow_verify && !ulen && d_off && r.seed_k >= 1 && n >= 4096 && n < (1ull << 32) && !aa_off) {
+    // amino batches of any lengths: the k-mer schedule with per-query lengths (queries it does not take are listed)
+    launch_aa_two_phase(r, d_q, d_off, n, 0, d_counts, d_ranges, d_status, s, nullptr);
+    return;
+  }
   const dim3 g(grid_for(r, n, 256)), b(256);
   const QueryList none{};
   if (r.dev.alphabet == NUCLEOTIDE)
@@ -867,26 +906,7 @@ void launch_count_ascii_uniform(Replica& r, const uint8_t* d_q, uint64_t n, uint
     launch_count_ascii(r, d_q, nullptr, n, d_counts, d_ranges, d_status, s, true, L);
     return;
   }
-  const unsigned nblk = (unsigned)r.num_cus * 8;  // both phases use this grid
-  const uint64_t per_block = ((n + (uint64_t)nblk * 256 - 1) / ((uint64_t)nblk * 256)) * 256;  // queries a block sees
-  if (sc->cap_q < per_block * nblk) {
-    HIP_CHECK(hipStreamSynchronize(s));
-    sc->q.alloc(per_block * nblk);
-    sc->cap_q = per_block * nblk;
-    sc->cap = 0;  // the nucleotide k-mer path re-allocates its three lists together
-  }
-  if (!sc->count.p) sc->count.alloc(nblk);
-  // the second pass works through all lists as one pool on a grid sized to what is resident at once (3 blocks per CU)
-  const bool pooled = nblk <= (unsigned)LIST_MAX_LISTS && !getenv("AWRY_AA_LIST_PER_BLOCK");
-  const QueryList ql{sc->q.p, sc->count.p, per_block, nullptr, nullptr, 0, d_tally, pooled ? nblk : 0u};
-  const unsigned nblk2 = pooled ? (unsigned)r.num_cus * 3 : nblk;
-  // Two queries in flight per lane (one: the same rate; four: 141 VGPRs, 10 % slower).  The second pass is a latency
-  // chain over a few per cent of the batch; running it for the first half of a batch on a side stream beside the first
-  // pass of the second half (event fork / join) was measured and costs more than it hides (12.7 -> 10.7 G present
-  // 12-mers/s, host path 0.83 -> 0.52 G queries/s).
-  hipLaunchKernelGGL(count_aa_kmer_probe_kernel<2>, dim3(nblk), dim3(256), 0, s, r.dev, d_q, n, (int)L, d_counts, d_ranges, d_status, ql);
-  hipLaunchKernelGGL((count_scalar_kernel<AMINO, LIST_BLOCK>), dim3(nblk2), dim3(256), 0, s, r.dev, d_q, nullptr, n, d_counts, d_ranges, d_status, 1, L, ql);
-  HIP_CHECK(hipGetLastError());
+  launch_aa_two_phase(r, d_q, nullptr, n, (int)L, d_counts, d_ranges, d_status, s, d_tally);
 }
 
 // pins a caller-owned host range for the duration of a batch so that H2D/D2H run as real async DMA

@@ -457,12 +457,15 @@ __device__ __forceinline__ uint32_t jn_idx(uint64_t i0, uint64_t i1, uint64_t i2
 constexpr int AA_KMER_VMULTI = 4;        // seed ranges of up to this many rows are verified candidate by candidate
 constexpr int AA_KMER_VMULTI_LANES = 8;  //   when at least this many lanes of the wave hold one
 
-template <int NQ>
-__global__ __launch_bounds__(256) void count_aa_kmer_probe_kernel(DevIndex ix, const uint8_t* __restrict__ ascii, uint64_t n, int L,
-                                                                  uint64_t* __restrict__ counts, uint64_t* __restrict__ ranges,
+// RAGGED: query q is ascii[off[q], off[q + 1]) with its own length (k .. AA_KMER_MAX residues take this pass, any other
+// length is listed for the generic kernel); L is then ignored.  Same per-lane work with the length, the number of
+// residues left of the seed window and the byte masks as per-lane values instead of wave constants.
+template <int NQ, bool RAGGED = false>
+__global__ __launch_bounds__(256) void count_aa_kmer_probe_kernel(DevIndex ix, const uint8_t* __restrict__ ascii, const uint64_t* __restrict__ off,
+                                                                  uint64_t n, int L, uint64_t* __restrict__ counts, uint64_t* __restrict__ ranges,
                                                                   uint8_t* __restrict__ status, QueryList ql) {
-  // per byte: bits 0..4 symbol index, bits 8..12 base-20 digit of a standard residue, bit 14 not a standard residue
-  // (X and every other letter search as X, index 20), bit 15 undefined in the reference ('$', '#', bytes >= 0x80)
+  // per byte: bits 0..4 symbol index, bits 8..12 digit of the seed-table index (the 21 searchable symbols), bit 15
+  // undefined in the reference ('$', '#', bytes >= 0x80)
   __shared__ uint16_t lut[256];
   __shared__ unsigned int s_count;
   {
@@ -474,17 +477,17 @@ __global__ __launch_bounds__(256) void count_aa_kmer_probe_kernel(DevIndex ix, c
   if (threadIdx.x == 0) s_count = 0;
   __syncthreads();
   const int lane = threadIdx.x & 63;
-  const int k = ix.seed_k, rem = L - k;
+  const int k = ix.seed_k;
   const SeedEntry* __restrict__ seed = ix.seed;
   const bool pos = ix.seed_pos && ix.text8 && ix.dense_sa && ix.dense_ratio == 1;
   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
   const uint64_t lane_lt = (1ull << lane) - 1;
   const uint64_t region = (uint64_t)blockIdx.x * ql.cap;
   auto bytes_mask = [](int m) { return m >= 8 ? ~0ull : (m <= 0 ? 0ull : (1ull << (8 * m)) - 1); };
-  const uint64_t m0 = bytes_mask(rem), m1 = bytes_mask(rem - 8), m2 = bytes_mask(rem - 16);
   auto ld8 = [](const uint8_t* p) { uint64_t v; __builtin_memcpy(&v, p, 8); return v; };
   // which of the candidates at text positions p[0 .. nc) have the query's first `rem` residues in front of them (bit c)
-  auto candidates = [&](const uint32_t (&p)[AA_KMER_VMULTI], uint32_t nc, uint64_t j0, uint64_t j1, uint64_t j2) {
+  auto candidates = [&](const uint32_t (&p)[AA_KMER_VMULTI], uint32_t nc, uint64_t j0, uint64_t j1, uint64_t j2, int rem) {
+    const uint64_t m0 = bytes_mask(rem), m1 = bytes_mask(rem - 8), m2 = bytes_mask(rem - 16);
     uint32_t found = 0;
 #pragma unroll
     for (int c = 0; c < AA_KMER_VMULTI; c++) {
@@ -500,17 +503,33 @@ __global__ __launch_bounds__(256) void count_aa_kmer_probe_kernel(DevIndex ix, c
   // the trip count is wave-uniform (ballots and the wave-level atomic below need every lane of the wave)
   for (uint64_t wbase = (uint64_t)blockIdx.x * blockDim.x + (threadIdx.x & ~63u); wbase < n; wbase += NQ * stride) {
     uint64_t qv[NQ], c0[NQ], c1[NQ], c2[NQ];
+    int Lq[NQ];      // residues of the query (RAGGED: its own; < 0 marks a length this pass does not take)
+    bool odd[NQ];    // RAGGED: length outside k .. AA_KMER_MAX
 #pragma unroll
-    for (int h = 0; h < NQ; h++) {  // bytes [0, 8), [8, 16), [16, 24) of the query, zero past its end
+    for (int h = 0; h < NQ; h++) {  // bytes [0, 8), [8, 16), [16, 24) of the query (bytes past its end are ignored below)
       qv[h] = wbase + lane + (uint64_t)h * stride;
       c0[h] = c1[h] = c2[h] = 0;
+      Lq[h] = L;
+      odd[h] = false;
       if (qv[h] < n) {
-        const uint8_t* p = ascii + qv[h] * (uint64_t)L;
-        c0[h] = ld8(p);
-        if (L > 8) {
-          const uint64_t last = ld8(p + L - 8);  // never reads past the query
-          if (L >= 16) { c1[h] = ld8(p + 8); if (L > 16) c2[h] = last >> (8 * (24 - L)); }
-          else c1[h] = last >> (8 * (16 - L));
+        if (RAGGED) {
+          const uint64_t b = off[qv[h]], len = off[qv[h] + 1] - b;
+          odd[h] = len < (uint64_t)(k > 1 ? k : 1) || len > (uint64_t)AA_KMER_MAX;
+          Lq[h] = odd[h] ? AA_KMER_MAX : (int)len;
+          if (!odd[h]) {  // (reads up to 7 bytes past the query: the buffer's documented slack covers the last one)
+            const uint8_t* p = ascii + b;
+            c0[h] = ld8(p);
+            if (len > 8) c1[h] = ld8(p + 8);
+            if (len > 16) c2[h] = ld8(p + 16);
+          }
+        } else {
+          const uint8_t* p = ascii + qv[h] * (uint64_t)L;
+          c0[h] = ld8(p);
+          if (L > 8) {
+            const uint64_t last = ld8(p + L - 8);  // never reads past the query
+            if (L >= 16) { c1[h] = ld8(p + 8); if (L > 16) c2[h] = last >> (8 * (24 - L)); }
+            else c1[h] = last >> (8 * (16 - L));
+          }
         }
       }
     }
@@ -519,13 +538,14 @@ __global__ __launch_bounds__(256) void count_aa_kmer_probe_kernel(DevIndex ix, c
     SeedEntry ev[NQ];
 #pragma unroll
     for (int h = 0; h < NQ; h++) {
-      uint32_t slot = 0, mul = 1, fl = 0;  // 21^7 < 2^32
+      const int len = Lq[h], rem = len - k;
+      uint32_t slot = 0, mul = 1, fl = odd[h] ? 0x4000u : 0u;  // 21^7 < 2^32
       auto word = [&](uint64_t c, int base) {
         uint64_t iw = 0;
 #pragma unroll
         for (int bj = 0; bj < 8; bj++) {
           const int j = base + bj;
-          if (j < L) {
+          if (j < len) {
             const uint32_t t = lut[(c >> (8 * bj)) & 0xFF];
             fl |= t & 0x8000u;
             iw |= (uint64_t)(t & 0x1Fu) << (8 * bj);
@@ -552,6 +572,7 @@ __global__ __launch_bounds__(256) void count_aa_kmer_probe_kernel(DevIndex ix, c
     for (int h = 0; h < NQ; h++) {
       const SeedEntry e = ev[h];
       const uint32_t scnt = aa_seed_cnt(e);
+      const int rem = Lq[h] - k;
       listed[h] = vfy[h] = multi[h] = false;
       value[h] = 0;
       rs[h] = (RS_PLAIN << RS_MODE_SHIFT) | 1ull;  // no hits
@@ -564,9 +585,8 @@ __global__ __launch_bounds__(256) void count_aa_kmer_probe_kernel(DevIndex ix, c
         else { value[h] = scnt; rs[h] = scnt == 1u && ix.seed_pos ? ((RS_SINGLE << RS_MODE_SHIFT) | e.sp) : ((RS_PLAIN << RS_MODE_SHIFT) | e.sp); }
       }
       else if (scnt == 1u) {
-        const int jn = rem - 1;  // the residue in front of the seed window must be BWT[row]
-        const uint64_t wn = jn < 8 ? i0[h] : (jn < 16 ? i1[h] : i2[h]);
-        if ((uint32_t)((wn >> (8 * (jn & 7))) & 0xFF) != aa_seed_sym(e)) value[h] = 0;
+        // the residue in front of the seed window must be BWT[row]
+        if (jn_idx(i0[h], i1[h], i2[h], rem - 1) != aa_seed_sym(e)) value[h] = 0;
         else if (aa_seed_is_ctx(e) && rem <= AA_SEED_CTX_LEN) {
           // the entry holds the residues in front of the one occurrence: decided here, no text access
           uint32_t qctx = 0;  // query residues rem-2, rem-3, ... 0 in the entry's order (rem <= 6: all in bytes 0..7)
@@ -585,15 +605,16 @@ __global__ __launch_bounds__(256) void count_aa_kmer_probe_kernel(DevIndex ix, c
             if (rem > 16) t2[h] = ld8(t + 16);
           }
         } else listed[h] = true;
-      } else if (aa_seed_is_multi(e) && !((aa_seed_mask(e) >> ((jn_idx(i0[h], i1[h], i2[h], rem - 1)) & 0x1Fu)) & 1u)) {
+      } else if (aa_seed_is_multi(e) && !((aa_seed_mask(e) >> (jn_idx(i0[h], i1[h], i2[h], rem - 1) & 0x1Fu)) & 1u)) {
         value[h] = 0;  // the residue in front of the seed window does not occur in the BWT over the entry's rows: absent
       } else if (pos && scnt <= (uint32_t)AA_KMER_VMULTI) multi[h] = true;
       else listed[h] = true;
     }
 #pragma unroll
     for (int h = 0; h < NQ; h++) {
+      const int rem = Lq[h] - k;
       if (vfy[h]) {
-        value[h] = (((t0[h] ^ i0[h]) & m0) | ((t1[h] ^ i1[h]) & m1) | ((t2[h] ^ i2[h]) & m2)) ? 0ull : 1ull;
+        value[h] = (((t0[h] ^ i0[h]) & bytes_mask(rem)) | ((t1[h] ^ i1[h]) & bytes_mask(rem - 8)) | ((t2[h] ^ i2[h]) & bytes_mask(rem - 16))) ? 0ull : 1ull;
         if (value[h]) rs[h] = (RS_SINGLE << RS_MODE_SHIFT) | ((uint64_t)ev[h].sp - (uint64_t)rem);
       }
       if (ql.tally) { const uint64_t vm = __ballot(vfy[h]); if (lane == 0) tally_add(ql.tally, 4, (unsigned long long)__popcll(vm)); }
@@ -609,7 +630,7 @@ __global__ __launch_bounds__(256) void count_aa_kmer_probe_kernel(DevIndex ix, c
         uint32_t p[AA_KMER_VMULTI];
 #pragma unroll
         for (int c = 0; c < AA_KMER_VMULTI; c++) p[c] = (uint32_t)c < nc ? ix.dense_sa[sp + c] : 0u;
-        const uint32_t mask = candidates(p, nc, i0[h], i1[h], i2[h]);
+        const uint32_t mask = candidates(p, nc, i0[h], i1[h], i2[h], rem);
         if (ql.tally) { tally_add(ql.tally, 3, nc); tally_add(ql.tally, 4, nc); }
         value[h] = (uint64_t)__popc(mask);
         rs[h] = (RS_MULTI << RS_MODE_SHIFT) | (uint64_t)sp | ((uint64_t)rem << 32) | ((uint64_t)mask << 48);

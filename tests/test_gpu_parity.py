@@ -1240,3 +1240,58 @@ def test_swissprot_scale_amino_12mers(oracle, tmp_path):
     rb = text[idx].copy()
     want, _ = oracle.OracleIndex.load(path).parallel_count(rb, ro, 8)
     assert np.array_equal(ix.parallel_count_csr(rb, ro), want)
+
+
+@pytest.mark.parametrize("lo,hi", [(1, 40), (8, 24), (5, 13)])
+def test_amino_kmer_schedule_with_unequal_lengths(oracle, lo, hi):
+    """amino batches of unequal lengths take the same two-phase schedule with per-query lengths (residues from the text,
+    random ones, X / unknown letters, lower case; lengths below the seed length and above 24 residues are listed for the
+    generic kernel): device-resident (awry_dev_count_ascii), parallel_count and parallel_locate against the oracle, with
+    several seed lengths and with the accelerators on and off"""
+    import torch
+    text, st, hd = synth.make_text(300000, 1, 93, 30, 0.02)
+    text = text.copy()
+    text[150000:151000] = text[3000:4000]
+    ix = gpu_index(text, 1, 8, 0, st, hd)
+    oi = oracle.OracleIndex.from_text(text, 1, 8, 0, st, hd)
+    rng = np.random.default_rng(lo * 100 + hi)
+    nq = 24000
+    lens = rng.integers(lo, hi + 1, size=nq)
+    qo = np.zeros(nq + 1, dtype=np.uint64)
+    qo[1:] = np.cumsum(lens)
+    starts = rng.integers(0, len(text) - hi - 2, size=nq)
+    starts[: nq // 8] = rng.integers(3000, 3900, size=nq // 8)
+    idx = np.repeat(starts, lens) + (np.arange(int(qo[-1])) - np.repeat(qo[:-1].astype(np.int64), lens))
+    qb = text[idx].copy()
+    rmask = np.repeat(rng.random(nq) < 0.4, lens)
+    qb[rmask] = synth.AA[rng.integers(0, 20, size=int(rmask.sum()))]
+    odd = rng.random(len(qb)) < 0.004
+    qb[odd] = np.frombuffer(b"XBZJ7*", dtype=np.uint8)[rng.integers(0, 6, size=int(odd.sum()))]
+    qb[qb == ord("$")] = ord("A")
+    low = np.repeat(rng.random(nq) < 0.1, lens)
+    qb[low] |= 0x20
+    want_loc = oi.parallel_locate(qb, qo, 4)[:3]
+    want = np.diff(want_loc[0])
+    assert (want > 1).sum() > 50 and (want == 0).sum() > 1000
+    dev = torch.device("cuda", 0)
+    d_q = torch.from_numpy(np.concatenate([qb, np.zeros(16, dtype=np.uint8)])).to(dev)
+    d_off = torch.from_numpy(qo.astype(np.int64)).to(dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    for verify in (2, -1):
+        ix.set_verify(verify)
+        for k in (-1, 3, 0):
+            ix.set_seed_kmer_len(k)
+            d_c = torch.full((nq,), -1, dtype=torch.int64, device=dev)
+            d_s = torch.full((nq,), 77, dtype=torch.uint8, device=dev)
+            ix.dev_count_ascii(d_q.data_ptr(), d_off.data_ptr(), nq, d_c.data_ptr(), None, d_s.data_ptr(), stream, 0)
+            torch.cuda.synchronize()
+            assert np.array_equal(d_c.cpu().numpy().astype(np.uint64), want), (verify, k)
+            assert int(d_s.max()) == 0
+            assert np.array_equal(ix.parallel_count_csr(qb, qo), want), (verify, k)
+            got = ix.parallel_locate_csr(qb, qo)
+            assert all(np.array_equal(x, y) for x, y in zip(got, want_loc)), (verify, k)
+    bad = qb.copy()
+    bad[int(qo[1234])] = ord("#")
+    with pytest.raises(AwryError) as e:
+        ix.parallel_count_csr(bad, qo)
+    assert e.value.code == ERR_INVALID_QUERY and "query 1234" in str(e.value)

@@ -1234,83 +1234,96 @@ void count_shard_generic_pipelined(Replica& r, const uint8_t* qbytes, const uint
   if (!ulen)  // (one length: the length scan has seen every offset already)
     for (uint64_t i = sh.lo; i < sh.hi; i++)  // (vectorises) non-decreasing offsets
       if (qoff[i + 1] < qoff[i]) throw ArgError("query offsets must be non-decreasing");
-  const std::vector<Shard> chunks = packed_chunks(qoff, sh, 4u << 20, 256ull << 20);
+  const std::vector<Shard> chunks = packed_chunks(qoff, sh, 1u << 20, 128ull << 20);
   uint64_t cap_q = 0, cap_b = 0;
   for (Shard c : chunks) { cap_q = std::max(cap_q, c.hi - c.lo); cap_b = std::max(cap_b, qoff[c.hi] - qoff[c.lo]); }
   std::lock_guard<std::mutex> lane_lock(r.lane_mu);
   static const bool trace = getenv("AWRY_TRACE_HOST") != nullptr;
   const auto t0 = std::chrono::steady_clock::now();
-  std::unique_ptr<HostPin> pin_out;
-  std::thread pin_out_thread([&] {
-    (void)hipSetDevice(r.device);
-    pin_out.reset(new HostPin(counts_out + sh.lo, (sh.hi - sh.lo) * 8));
-  });
-  struct Joiner {
-    std::thread& t;
-    ~Joiner() { if (t.joinable()) t.join(); }
-  } joiner{pin_out_thread};
-  HostPin pin_in(qbytes + qoff[sh.lo], qoff[sh.hi] - qoff[sh.lo]), pin_off(ulen ? nullptr : qoff + sh.lo, (sh.hi - sh.lo + 1) * 8);
-  const auto t1 = std::chrono::steady_clock::now();
+  // Like the host-packed lanes: the chunk's bytes (and offsets) are copied by the pool into the lane's pinned staging --
+  // nothing of the caller's is registered with the driver --, counts come back as 32-bit words when they fit (a count is
+  // at most bwt_len) and are widened into counts_out, and instead of one status byte per query the lowest rejected
+  // query crosses PCIe as one word.
+  const bool narrow32 = r.dev.bwt_len < (1ull << 32);
   PackedLane* lanes = r.lanes;
+  double t_stage = 0, t_wait = 0, t_out = 0;
+  auto now = [] { return std::chrono::steady_clock::now(); };
+  auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
   auto retire = [&](PackedLane& ln) {
     if (!ln.busy) return;
     ln.busy = false;
+    auto a = now();
     HIP_CHECK(hipEventSynchronize(ln.done));
+    auto b = now();
     const uint64_t n = ln.chunk_hi - ln.chunk_lo;
-    const uint8_t* st = ln.h_status.p;
-    uint64_t any = 0;
-    for (uint64_t i = 0; i < n; i++) any |= st[i];
-    if (any) {
+    if (narrow32) pool_widen_u32(counts_out + ln.chunk_lo, ln.h_counts32.p, n);
+    else pool_memcpy(counts_out + ln.chunk_lo, ln.h_words.p, n * 8);
+    if (trace) { t_wait += ms(a, b); t_out += ms(b, now()); }
+    if (ln.h_bad[1] != ~0ull) {
       ChunkBuffers cb;
-      cb.h_status.assign(st, st + n);
-      check_status(cb, ln.chunk_lo);  // raises INVALID_QUERY naming the first such query
+      cb.h_status.assign(1, (uint8_t)(ln.h_bad[1] & 0xFF));
+      check_status(cb, ln.chunk_lo + (ln.h_bad[1] >> 8));  // raises INVALID_QUERY naming the first such query
     }
   };
   struct Drain {
     Replica& r;
     ~Drain() {
-      for (int li = 0; li < 2; li++)
+      for (int li = 0; li < Replica::NLANES; li++)
         if (r.lanes[li].busy) { (void)hipStreamSynchronize(r.lane_stream[li]); r.lanes[li].busy = false; }
     }
   } drain{r};
-  for (int li = 0; li < 2; li++) {
+  const int nl = (int)std::min<size_t>(Replica::NLANES, chunks.size());
+  for (int li = 0; li < nl; li++) {
     PackedLane& ln = lanes[li];
     ln.s = r.lane_stream[li];
     if (!ln.done) HIP_CHECK(hipEventCreateWithFlags(&ln.done, hipEventDisableTiming));
+    if (!ln.h_bad) HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&ln.h_bad), 16, hipHostMallocDefault));
+    ln.h_bbytes.ensure(cap_b + 16);
     if (ln.ascii.n < cap_b + 16) ln.ascii.alloc(cap_b + 16);
-    if (!ulen && ln.off.n < cap_q + 1) ln.off.alloc(cap_q + 1);
+    if (!ulen) { ln.h_boff.ensure(cap_q + 1); if (ln.off.n < cap_q + 1) ln.off.alloc(cap_q + 1); }
     if (ln.counts.n < cap_q) ln.counts.alloc(cap_q);
     if (ln.status.n < cap_q) ln.status.alloc(cap_q);
-    ln.h_status.ensure(cap_q);
+    if (ln.bad.n < 2) ln.bad.alloc(2);
+    if (narrow32) { ln.h_counts32.ensure(cap_q); if (ln.counts32.n < cap_q) ln.counts32.alloc(cap_q); }
+    else ln.h_words.ensure(cap_q);  // (pinned staging of the 64-bit counts)
   }
   int which = 0;
   for (Shard c : chunks) {
     PackedLane& ln = lanes[which];
-    which ^= 1;
+    which = (which + 1) % nl;
     retire(ln);
     const uint64_t lo = c.lo, hi = c.hi, n = hi - lo, base = qoff[lo], nbytes = qoff[hi] - base;
     ln.chunk_lo = lo;
     ln.chunk_hi = hi;
-    if (nbytes) HIP_CHECK(hipMemcpyAsync(ln.ascii.p, qbytes + base, nbytes, hipMemcpyHostToDevice, ln.s));
+    auto a = now();
+    if (nbytes) pool_memcpy(ln.h_bbytes.p, qbytes + base, nbytes);
+    if (!ulen) pool_memcpy(ln.h_boff.p, qoff + lo, (n + 1) * 8);
+    if (trace) t_stage += ms(a, now());
+    if (nbytes) HIP_CHECK(hipMemcpyAsync(ln.ascii.p, ln.h_bbytes.p, nbytes, hipMemcpyHostToDevice, ln.s));
     if (ulen) {
       launch_count_ascii_uniform(r, ln.ascii.p, n, ulen, ln.counts.p, ln.status.p, ln.s);
     } else {
-      HIP_CHECK(hipMemcpyAsync(ln.off.p, qoff + lo, (n + 1) * 8, hipMemcpyHostToDevice, ln.s));
+      HIP_CHECK(hipMemcpyAsync(ln.off.p, ln.h_boff.p, (n + 1) * 8, hipMemcpyHostToDevice, ln.s));
       const uint8_t* biased = reinterpret_cast<const uint8_t*>(reinterpret_cast<uintptr_t>(ln.ascii.p) - base);
       launch_count_ascii(r, biased, ln.off.p, n, ln.counts.p, nullptr, ln.status.p, ln.s, true);
     }
-    if (pin_out_thread.joinable()) pin_out_thread.join();
-    HIP_CHECK(hipMemcpyAsync(counts_out + lo, ln.counts.p, n * 8, hipMemcpyDeviceToHost, ln.s));
-    HIP_CHECK(hipMemcpyAsync(ln.h_status.p, ln.status.p, n, hipMemcpyDeviceToHost, ln.s));
+    HIP_CHECK(hipMemsetAsync(ln.bad.p + 1, 0xFF, 8, ln.s));
+    hipLaunchKernelGGL(status_first_bad_kernel, dim3(grid_for(r, n, 4096)), dim3(256), 0, ln.s, ln.status.p, n, ln.bad.p + 1);
+    if (narrow32) {
+      hipLaunchKernelGGL(narrow_counts_kernel, dim3(grid_for(r, n, 1024)), dim3(256), 0, ln.s, ln.counts.p, ln.counts32.p, n);
+      HIP_CHECK(hipMemcpyAsync(ln.h_counts32.p, ln.counts32.p, n * 4, hipMemcpyDeviceToHost, ln.s));
+    } else {
+      HIP_CHECK(hipMemcpyAsync(ln.h_words.p, ln.counts.p, n * 8, hipMemcpyDeviceToHost, ln.s));
+    }
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipMemcpyAsync(ln.h_bad + 1, ln.bad.p + 1, 8, hipMemcpyDeviceToHost, ln.s));
     HIP_CHECK(hipEventRecord(ln.done, ln.s));
     ln.busy = true;
   }
-  for (int li = 0; li < 2; li++) retire(lanes[li]);
-  if (trace) {
-    auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
-    fprintf(stderr, "[awry] generic shard %llu queries%s: pin %.2f ms, pipeline %.2f ms\n", (unsigned long long)(sh.hi - sh.lo),
-            ulen ? " (one length)" : "", ms(t0, t1), ms(t1, std::chrono::steady_clock::now()));
-  }
+  for (int k2 = 0; k2 < nl; k2++) { retire(lanes[which]); which = (which + 1) % nl; }
+  if (trace)
+    fprintf(stderr, "[awry] generic shard %llu queries%s, %zu chunks: %.2f ms (staging %.2f, waiting for the GPU %.2f, copying counts out %.2f)\n",
+            (unsigned long long)(sh.hi - sh.lo), ulen ? " (one length)" : "", chunks.size(), ms(t0, now()), t_stage, t_wait, t_out);
 }
 
 void count_shard(Replica& r, const uint8_t* qbytes, const uint64_t* qoff, Shard sh, uint64_t* counts_out) {

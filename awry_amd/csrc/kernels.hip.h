@@ -663,6 +663,16 @@ __global__ __launch_bounds__(256) void narrow_counts_kernel(const uint64_t* __re
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = (uint32_t)in[i];
 }
 
+// the lowest query of a chunk that the generic kernel rejected, as (index << 8 | status), or ~0: eight bytes cross PCIe
+// instead of one status byte per query
+__global__ __launch_bounds__(256) void status_first_bad_kernel(const uint8_t* __restrict__ status, uint64_t n, unsigned long long* __restrict__ first_bad) {
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  unsigned long long best = ~0ull;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+    if (status[i] != Q_OK) { const unsigned long long v = ((unsigned long long)i << 8) | status[i]; best = v < best ? v : best; }
+  if (best != ~0ull) atomicMin(first_bad, best);
+}
+
 // one step / one backstep / one initial range for the scalar conveniences of the C ABI
 template <int A>
 __global__ void scalar_ops_kernel(DevIndex ix, int op, uint64_t a, uint64_t b, int idx, uint64_t* out) {

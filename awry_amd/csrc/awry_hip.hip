@@ -1380,8 +1380,76 @@ void count_shard_generic(Replica& r, const uint8_t* qbytes, const uint64_t* qoff
   }
 }
 
+// Result arrays of the batch entry points (offsets, positions, (record, offset) pairs) are PINNED host memory, recycled
+// through a process-wide pool: the locate kernels' output is copied by the DMA engine straight into the array the caller
+// receives -- no pinned staging, no host memcpy, and after the first call no first-touch page faults either (a fresh
+// 100 MB array costs more in faults than its bytes cost on PCIe).  awry_free_buffer returns a block to the pool; blocks
+// are kept up to AWRY_PINNED_CACHE_GB (default 4) and otherwise released.  Where pinning fails the arrays are plain
+// malloc memory and the copies are staged by the runtime.
+class PinnedPool {
+ public:
+  static PinnedPool& instance() {
+    static PinnedPool* pool = new PinnedPool;  // never destroyed: the HIP runtime may be gone before static destructors run
+    return *pool;
+  }
+  void* get(size_t bytes) {  // >= bytes of pinned memory, or nullptr
+    const size_t want = round_up(bytes);
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      auto it = free_.lower_bound(want);
+      if (it != free_.end() && it->first <= 2 * want) {
+        void* p = it->second;
+        cached_ -= it->first;
+        live_[p] = it->first;
+        free_.erase(it);
+        return p;
+      }
+    }
+    void* p = nullptr;
+    if (hipHostMalloc(&p, want, hipHostMallocPortable) != hipSuccess || !p) { (void)hipGetLastError(); return nullptr; }
+    std::lock_guard<std::mutex> lk(mu_);
+    live_[p] = want;
+    return p;
+  }
+  bool put(void* p) {  // false: not a block of this pool
+    size_t bytes = 0;
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      auto it = live_.find(p);
+      if (it == live_.end()) return false;
+      bytes = it->second;
+      live_.erase(it);
+      if (cached_ + bytes <= cap_) {
+        free_.emplace(bytes, p);
+        cached_ += bytes;
+        return true;
+      }
+    }
+    (void)hipHostFree(p);
+    return true;
+  }
+ private:
+  PinnedPool() {
+    const char* e = getenv("AWRY_PINNED_CACHE_GB");
+    cap_ = (size_t)((e && atof(e) >= 0 ? atof(e) : 4.0) * (double)(1ull << 30));
+  }
+  static size_t round_up(size_t b) {  // 1 MiB, then powers of two up to 64 MiB, then multiples of 64 MiB
+    size_t c = 1u << 20;
+    while (c < b && c < (64u << 20)) c <<= 1;
+    return c >= b ? c : (b + (64u << 20) - 1) / (64u << 20) * (64u << 20);
+  }
+  std::mutex mu_;
+  std::multimap<size_t, void*> free_;
+  std::map<void*, size_t> live_;
+  size_t cached_ = 0, cap_ = 0;
+};
+
+void release_result(void* p) {
+  if (p && !PinnedPool::instance().put(p)) free(p);
+}
+
 template <class T>
-struct MBuf {  // malloc'ed, geometrically growing array whose storage can be handed to the caller (awry_free_buffer = free)
+struct MBuf {  // geometrically growing result array whose storage is handed to the caller (released with awry_free_buffer)
   T* p = nullptr;
   size_t cap = 0;
   size_t used_bytes = 0;  // bytes of p[] that hold data (what a re-allocation has to carry over)
@@ -1389,25 +1457,16 @@ struct MBuf {  // malloc'ed, geometrically growing array whose storage can be ha
   MBuf(const MBuf&) = delete;
   MBuf& operator=(const MBuf&) = delete;
   MBuf(MBuf&& o) noexcept : p(o.p), cap(o.cap), used_bytes(o.used_bytes) { o.p = nullptr; o.cap = 0; o.used_bytes = 0; }
-  ~MBuf() { free(p); }
+  ~MBuf() { release_result(p); }
   void grow(size_t need) {
     if (need <= cap) return;
     const size_t c = std::max(need, cap + cap / 2 + 4096), bytes = c * sizeof(T);
-    if (bytes >= (8u << 20)) {
-      // result-sized: 2 MB-aligned and advised for huge pages -- filling a fresh array is bound by its first-touch page
-      // faults, and a huge page takes one fault for 512 small ones (no effect where the kernel has them switched off)
-      void* q = nullptr;
-      if (posix_memalign(&q, 2u << 20, bytes) != 0 || !q) throw std::bad_alloc();
-      (void)madvise(q, bytes, MADV_HUGEPAGE);
-      if (p && used_bytes) memcpy(q, p, used_bytes);
-      free(p);
-      p = static_cast<T*>(q);
-      cap = c;
-      return;
-    }
-    T* q = static_cast<T*>(realloc(p, bytes));
+    void* q = bytes >= (256u << 10) ? PinnedPool::instance().get(bytes) : nullptr;
+    if (!q) q = malloc(bytes);
     if (!q) throw std::bad_alloc();
-    p = q;
+    if (p && used_bytes) pool_memcpy(q, p, used_bytes);
+    release_result(p);
+    p = static_cast<T*>(q);
     cap = c;
   }
   T* release() { T* q = p; p = nullptr; cap = 0; used_bytes = 0; return q; }
@@ -1419,29 +1478,36 @@ struct LocateResult {  // per shard, in query order
   uint64_t nq = 0, filled = 0, running = 0;
   MBuf<uint64_t> gpos;
   MBuf<awry_pos_t> pos;
-  size_t total = 0;
+  size_t total = 0;      // hits whose results are in (or on their way into) the arrays
   bool want_pos = true;  // false: the caller passed hits_out == NULL -- (record, offset) pairs are neither computed nor moved
   void add_counts(const uint64_t* counts, uint64_t n) {  // next n queries of the shard
     for (uint64_t i = 0; i < n; i++) { running += counts[i]; off[filled + i + 1] = running; }
     filled += n;
   }
+  // next n queries of the shard, whose inclusive hit offsets RELATIVE TO THE CHUNK already sit in off[filled + 1 ...]
+  // (copied there from the device scan): rebase them onto the shard's running total
+  void rebase_offsets(uint64_t n, uint64_t chunk_total) {
+    uint64_t* o = off + filled + 1;
+    const uint64_t base = running;
+    if (base) HostPool::instance().run_ranges(n, 1u << 16, [&](uint64_t a, uint64_t b) { for (uint64_t i = a; i < b; i++) o[i] += base; });
+    running += chunk_total;
+    filled += n;
+  }
+  // room for n more hits; true when an array moved (copies in flight into the old one must have finished: see `quiesce`)
+  template <class Quiesce>
+  void reserve(size_t n, bool want_gpos, Quiesce&& quiesce) {
+    if ((!want_pos || total + n <= pos.cap) && (!want_gpos || total + n <= gpos.cap)) return;
+    size_t need = total + n;
+    if (filled && filled < nq) need = std::max(need, (size_t)((double)(total + n) / (double)filled * (double)nq * 1.05) + 4096);  // the whole shard, from the hit rate so far
+    quiesce();
+    if (want_pos) { pos.used_bytes = total * sizeof(awry_pos_t); pos.grow(need); }
+    if (want_gpos) { gpos.used_bytes = total * 8; gpos.grow(need); }
+  }
   void append(const uint64_t* g, const awry_pos_t* p, size_t n, bool want_gpos) {
     if (!n) return;
-    if (total + n > std::max(pos.cap, gpos.cap) && filled && filled < nq) {  // size the arrays for the whole shard from the hit rate so far
-      const size_t est = (size_t)((double)(total + n) / (double)filled * (double)nq * 1.05) + 4096;
-      if (want_pos) pos.grow(est);
-      if (want_gpos) gpos.grow(est);
-    }
-    if (want_pos) {
-      pos.grow(total + n);
-      pool_memcpy(pos.p + total, p, n * sizeof(awry_pos_t));
-      pos.used_bytes = (total + n) * sizeof(awry_pos_t);
-    }
-    if (want_gpos) {
-      gpos.grow(total + n);
-      pool_memcpy(gpos.p + total, g, n * 8);
-      gpos.used_bytes = (total + n) * 8;
-    }
+    reserve(n, want_gpos, [] {});
+    if (want_pos) pool_memcpy(pos.p + total, p, n * sizeof(awry_pos_t));
+    if (want_gpos) pool_memcpy(gpos.p + total, g, n * 8);
     total += n;
   }
 };
@@ -1517,7 +1583,7 @@ void locate_shard_packed(Replica& r, const uint8_t* qbytes, const uint64_t* qoff
   std::vector<uint32_t> bad;
   double t_pack = 0;
   LocateLane* lanes = r.loc_lanes;
-  double t_pin = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), t_wait_count = 0, t_wait_locate = 0, t_append = 0;
+  double t_pin = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), t_wait_count = 0, t_wait_locate = 0;
   auto timed = [&](double& acc, auto&& fn) {
     if (!trace) { fn(); return; }
     const auto a = std::chrono::steady_clock::now();
@@ -1550,7 +1616,6 @@ void locate_shard_packed(Replica& r, const uint8_t* qbytes, const uint64_t* qoff
     if (ln.hit_off.n < cap + 1) ln.hit_off.alloc(cap + 1);
     if (ln.scratch.n < scan_tiles(cap) + 1) ln.scratch.alloc(scan_tiles(cap) + 1);
     if (ln.bad.n < 2) ln.bad.alloc(2);
-    ln.h_counts.ensure(cap);
     ln.h_meta.ensure(3);
     ln.stage = 0;
   }
@@ -1600,7 +1665,7 @@ void locate_shard_packed(Replica& r, const uint8_t* qbytes, const uint64_t* qoff
       launch_scan(r, ln.counts.p, n, ln.hit_off.p, ln.scratch.p, s);
       HIP_CHECK(hipMemcpyAsync(ln.h_meta.p, ln.hit_off.p + n, 8, hipMemcpyDeviceToHost, s));
       HIP_CHECK(hipMemcpyAsync(ln.h_meta.p + 1, ln.bad.p, 16, hipMemcpyDeviceToHost, s));
-      HIP_CHECK(hipMemcpyAsync(ln.h_counts.p, ln.counts.p, n * 8, hipMemcpyDeviceToHost, s));
+      HIP_CHECK(hipMemcpyAsync(out.off + (lo - sh.lo) + 1, ln.hit_off.p + 1, n * 8, hipMemcpyDeviceToHost, s));  // chunk-relative; rebased in stage 2
       HIP_CHECK(hipEventRecord(ln.counted, s));
       ln.stage = 1;
       return;
@@ -1630,7 +1695,7 @@ void locate_shard_packed(Replica& r, const uint8_t* qbytes, const uint64_t* qoff
     launch_scan(r, ln.counts.p, n, ln.hit_off.p, ln.scratch.p, s);
     HIP_CHECK(hipMemcpyAsync(ln.h_meta.p, ln.hit_off.p + n, 8, hipMemcpyDeviceToHost, s));
     HIP_CHECK(hipMemcpyAsync(ln.h_meta.p + 1, ln.bad.p, 16, hipMemcpyDeviceToHost, s));
-    HIP_CHECK(hipMemcpyAsync(ln.h_counts.p, ln.counts.p, n * 8, hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipMemcpyAsync(out.off + (lo - sh.lo) + 1, ln.hit_off.p + 1, n * 8, hipMemcpyDeviceToHost, s));  // chunk-relative; rebased in stage 2
     HIP_CHECK(hipEventRecord(ln.counted, s));
     ln.stage = 1;
   };
@@ -1654,35 +1719,20 @@ void locate_shard_packed(Replica& r, const uint8_t* qbytes, const uint64_t* qoff
       cb.h_status.assign(1, (uint8_t)(ln.h_meta.p[2] & 0xFF));
       check_status(cb, ln.lo + (ln.h_meta.p[2] >> 8));
     }
-    out.add_counts(ln.h_counts.p, n);  // stage 2 runs in chunk order
     ln.total = ln.h_meta.p[0];
-    const uint64_t STAGE_CAP = 16ull << 20;  // hits the pinned staging of a lane holds at most (384 MB)
-    if (ln.total > STAGE_CAP) {
-      // a hit-heavy chunk (repeats, N runs): the positions come back in pieces through the bounded staging, appended
-      // here -- every earlier chunk has been appended already (stage 3 of chunk i - 2 runs before stage 1 of chunk i)
-      if (ln.gpos.n < ln.total) ln.gpos.alloc(ln.total + ln.total / 4);
-      if (want_pos && ln.pos.n < 2 * ln.total) ln.pos.alloc(2 * (ln.total + ln.total / 4));
-      if (want_pos) ln.h_pos.ensure(STAGE_CAP);
-      if (want_gpos) ln.h_gpos.ensure(STAGE_CAP);
-      launch_locate(r, ln.rstart.p, generic ? 2 : 1, ln.hit_off.p, n, ln.total, ln.gpos.p, want_pos ? ln.pos.p : nullptr, s);
-      for (uint64_t at = 0; at < ln.total; at += STAGE_CAP) {
-        const uint64_t m = std::min(STAGE_CAP, ln.total - at);
-        if (want_pos) HIP_CHECK(hipMemcpyAsync(ln.h_pos.p, ln.pos.p + 2 * at, m * 16, hipMemcpyDeviceToHost, s));
-        if (want_gpos) HIP_CHECK(hipMemcpyAsync(ln.h_gpos.p, ln.gpos.p + at, m * 8, hipMemcpyDeviceToHost, s));
-        HIP_CHECK(hipStreamSynchronize(s));
-        out.append(ln.h_gpos.p, ln.h_pos.p, m, want_gpos);
-      }
-      ln.stage = 0;
-      return;
-    }
+    out.rebase_offsets(n, ln.total);  // stage 2 runs in chunk order
     if (ln.total) {
+      // the positions go from the device straight into the result arrays (pinned, PinnedPool): no staging, no host copy.
+      // An array that has to grow first waits for the copies still on their way into it.
+      out.reserve(ln.total, want_gpos, [&] {
+        for (int l2 = 0; l2 < 2; l2++) HIP_CHECK(hipStreamSynchronize(r.lane_stream[l2]));
+      });
       if (ln.gpos.n < ln.total) ln.gpos.alloc(ln.total + ln.total / 4);
       if (want_pos && ln.pos.n < 2 * ln.total) ln.pos.alloc(2 * (ln.total + ln.total / 4));
-      if (want_pos) ln.h_pos.ensure(ln.total);
-      if (want_gpos) ln.h_gpos.ensure(ln.total);
       launch_locate(r, ln.rstart.p, generic ? 2 : 1, ln.hit_off.p, n, ln.total, ln.gpos.p, want_pos ? ln.pos.p : nullptr, s);
-      if (want_pos) HIP_CHECK(hipMemcpyAsync(ln.h_pos.p, ln.pos.p, ln.total * 16, hipMemcpyDeviceToHost, s));
-      if (want_gpos) HIP_CHECK(hipMemcpyAsync(ln.h_gpos.p, ln.gpos.p, ln.total * 8, hipMemcpyDeviceToHost, s));
+      if (want_pos) HIP_CHECK(hipMemcpyAsync(out.pos.p + out.total, ln.pos.p, ln.total * 16, hipMemcpyDeviceToHost, s));
+      if (want_gpos) HIP_CHECK(hipMemcpyAsync(out.gpos.p + out.total, ln.gpos.p, ln.total * 8, hipMemcpyDeviceToHost, s));
+      out.total += ln.total;
     }
     HIP_CHECK(hipEventRecord(ln.located, s));
     ln.stage = 2;
@@ -1691,7 +1741,6 @@ void locate_shard_packed(Replica& r, const uint8_t* qbytes, const uint64_t* qoff
     LocateLane& ln = lanes[li];
     if (ln.stage != 2) return;
     timed(t_wait_locate, [&] { HIP_CHECK(hipEventSynchronize(ln.located)); });
-    timed(t_append, [&] { out.append(ln.h_gpos.p, ln.h_pos.p, ln.total, want_gpos); });
     ln.stage = 0;
   };
   uint64_t i = 0;
@@ -1703,13 +1752,13 @@ void locate_shard_packed(Replica& r, const uint8_t* qbytes, const uint64_t* qoff
     i++;
   }
   const int last = (int)((i + 1) & 1);            // lane of chunk i - 1
-  stage3(last ^ 1);                               // chunk i - 2 first: stage 2 may append a hit-heavy chunk itself
+  stage3(last ^ 1);                               // chunk i - 2
   stage2(last);
   stage3(last);
   if (trace)
-    fprintf(stderr, "[awry] packed locate shard: %llu reads, %zu hits, %.2f ms (pin %.2f, host pack %.2f, waiting for counts %.2f, for positions %.2f, copying out %.2f)\n",
+    fprintf(stderr, "[awry] packed locate shard: %llu reads, %zu hits, %.2f ms (pin %.2f, host pack %.2f, waiting for counts %.2f, for positions %.2f; results land in the caller's arrays by DMA)\n",
             (unsigned long long)(sh.hi - sh.lo), out.total, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(),
-            t_pin, t_pack, t_wait_count, t_wait_locate, t_append);
+            t_pin, t_pack, t_wait_count, t_wait_locate);
 }
 
 void locate_shard(Replica& r, const uint8_t* qbytes, const uint64_t* qoff, Shard sh, bool want_gpos, LocateResult& out) {
@@ -2015,11 +2064,12 @@ int awry_locate_batch(awry_index_t* idx, const uint8_t* qbytes, const uint64_t* 
     const auto t0 = std::chrono::steady_clock::now();
     std::vector<LocateResult> res(std::max<size_t>(1, idx->reps.size()));
     for (auto& x : res) x.want_pos = hits_out != nullptr;
-    std::unique_ptr<uint64_t, decltype(&free)> off(malloc_array<uint64_t>(n + 1), &free);
-    off.get()[0] = 0;
+    MBuf<uint64_t> off;  // pinned (PinnedPool): the shards' device scans are copied straight into it
+    off.grow(n + 1);
+    off.p[0] = 0;
     {
       auto shards = shard_queries(n, res.size());  // the same cut for_each_replica makes
-      for (size_t g = 0; g < res.size(); g++) res[g].off = off.get() + shards[g].lo;
+      for (size_t g = 0; g < res.size(); g++) res[g].off = off.p + shards[g].lo;
     }
     for_each_replica(idx, n, [&](Replica& r, Shard sh, int g) { locate_shard(r, qbytes, qoff, sh, global_pos_out != nullptr, res[g]); });
     uint64_t total = 0;
@@ -2032,12 +2082,14 @@ int awry_locate_batch(awry_index_t* idx, const uint8_t* qbytes, const uint64_t* 
       if (hits_out) *hits_out = res[0].pos.release();
       if (global_pos_out) *global_pos_out = res[0].gpos.release();
     } else {
-      std::unique_ptr<awry_pos_t, decltype(&free)> hits(hits_out ? malloc_array<awry_pos_t>(total) : nullptr, &free);
-      std::unique_ptr<uint64_t, decltype(&free)> gp(global_pos_out ? malloc_array<uint64_t>(total) : nullptr, &free);
+      MBuf<awry_pos_t> hits;
+      MBuf<uint64_t> gp;
+      if (hits_out) hits.grow(std::max<uint64_t>(1, total));
+      if (global_pos_out) gp.grow(std::max<uint64_t>(1, total));
       uint64_t at = 0;
       for (auto& x : res) {
-        if (hits && x.total) pool_memcpy(hits.get() + at, x.pos.p, x.total * sizeof(awry_pos_t));
-        if (gp && x.total) pool_memcpy(gp.get() + at, x.gpos.p, x.total * 8);
+        if (hits_out && x.total) pool_memcpy(hits.p + at, x.pos.p, x.total * sizeof(awry_pos_t));
+        if (global_pos_out && x.total) pool_memcpy(gp.p + at, x.gpos.p, x.total * 8);
         at += x.total;
       }
       if (hits_out) *hits_out = hits.release();
@@ -2049,7 +2101,7 @@ int awry_locate_batch(awry_index_t* idx, const uint8_t* qbytes, const uint64_t* 
   });
 }
 
-void awry_free_buffer(void* p) { free(p); }
+void awry_free_buffer(void* p) { release_result(p); }
 
 namespace {
 // one query through the replica's pinned mailbox; want_rows: the range must be a row interval (no text shortcut)
@@ -2147,7 +2199,7 @@ int awry_locate(awry_index_t* idx, const uint8_t* q, uint64_t len, awry_pos_t** 
   int rc = awry_locate_batch(idx, q, off, 1, &hit_off, hits_out, global_pos_out);
   if (rc == AWRY_OK) {
     if (n_hits) *n_hits = hit_off[1];
-    free(hit_off);
+    release_result(hit_off);
   }
   return rc;
 }

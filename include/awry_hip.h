@@ -123,6 +123,9 @@ int awry_count_packed_kmers(awry_index_t *idx, const uint64_t *words, uint64_t n
  * are neither computed nor moved; with both NULL the call returns the offsets alone. */
 int awry_locate_batch(awry_index_t *idx, const uint8_t *qbytes, const uint64_t *qoff, uint64_t n,
                       uint64_t **hit_off_out, awry_pos_t **hits_out, uint64_t **global_pos_out);
+/* releases an array one of the calls above (or awry_locate / awry_read_query_file) returned.  Result arrays are pinned
+ * host memory recycled through a process-wide pool (the device writes results straight into them); never pass them to
+ * free().  AWRY_PINNED_CACHE_GB (default 4) bounds what the pool keeps between calls. */
 void awry_free_buffer(void *p);
 
 /* ---- scalar conveniences (each launches on replica 0) ---------------------------------------------- */

@@ -119,12 +119,26 @@ uint8_t orc_block_code_at(const uint64_t *planes, int nplanes, uint64_t pos) {
   return code;
 }
 
+/* Vec256 and its three boolean ops: src/simd_instructions.rs:35-54,78-94.  With AVX2 (the build's -march=x86-64-v3, as
+ * the reference's x86-64 back-end) they are the same intrinsics the reference uses -- _mm256_and_si256, _mm256_or_si256,
+ * _mm256_andnot_si256 -- and the popcount stays four scalar popcnt over the extracted lanes (:96-121); without AVX2
+ * (sanitizer builds with other flags) plain C over the four words. */
+#if defined(__AVX2__)
+#include <immintrin.h>
+typedef union { __m256i v; uint64_t w[4]; } v256;
+static inline v256 ld(const uint64_t *p) { v256 r; r.v = _mm256_loadu_si256((const __m256i *)p); return r; }
+static inline v256 AND(v256 a, v256 b) { a.v = _mm256_and_si256(a.v, b.v); return a; }
+static inline v256 OR(v256 a, v256 b) { a.v = _mm256_or_si256(a.v, b.v); return a; }
+/* andnot(x, y) = !x & y : src/simd_instructions.rs:89-94 (the intrinsic's own operand order) */
+static inline v256 ANDN(v256 a, v256 b) { a.v = _mm256_andnot_si256(a.v, b.v); return a; }
+#else
 typedef struct { uint64_t w[4]; } v256;
 static inline v256 ld(const uint64_t *p) { v256 r; memcpy(r.w, p, 32); return r; }
 static inline v256 AND(v256 a, v256 b) { for (int i = 0; i < 4; i++) a.w[i] &= b.w[i]; return a; }
 static inline v256 OR(v256 a, v256 b) { for (int i = 0; i < 4; i++) a.w[i] |= b.w[i]; return a; }
 /* andnot(x, y) = !x & y : src/simd_instructions.rs:89-94 */
 static inline v256 ANDN(v256 a, v256 b) { for (int i = 0; i < 4; i++) a.w[i] = ~a.w[i] & b.w[i]; return a; }
+#endif
 
 /* src/bwt.rs:114-135 */
 uint64_t orc_nt_block_occ(const uint64_t planes[12], const uint64_t ms[8], uint64_t pos, uint8_t sym) {

@@ -1,0 +1,50 @@
+"""Condenses a `rocprofv3 --kernel-trace --stats` run of bench.py into the JSON committed under profiles/: per kernel the
+calls, average / min / max duration, and -- cut by the bench's phase markers -- the average duration inside each phase,
+next to the HIP-event figure the bench line of the same run printed.
+usage: summarize_trace.py <rocprofv3 output dir> <bench json of that run>"""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import OrderedDict, defaultdict
+
+root, bench_json = sys.argv[1], sys.argv[2]
+PHASES = ["headline?"]  # phase ids are assigned in bench.py in the order the phases run; names come from the bench line
+
+
+def short(n):
+    return n.split("(")[0].replace("awry::", "").replace("(anonymous namespace)::", "").replace("void ", "")
+
+
+out = OrderedDict()
+for f in glob.glob(os.path.join(root, "**", "*kernel_stats.csv"), recursive=True):
+    rows = list(csv.DictReader(open(f)))
+    out["kernel_stats_top"] = [{"name": short(r["Name"])[:100], "calls": int(r["Calls"]), "avg_us": float(r["AverageNs"]) / 1e3,
+                                "min_us": float(r["MinNs"]) / 1e3, "max_us": float(r["MaxNs"]) / 1e3, "percent": float(r["Percentage"])}
+                               for r in rows[:25]]
+rows = []
+for f in glob.glob(os.path.join(root, "**", "*kernel_trace.csv"), recursive=True):
+    rows += list(csv.DictReader(open(f)))
+rows.sort(key=lambda r: int(r["Dispatch_Id"]))
+# the timed loop of the headline runs before any marker (markers only bracket the variants): everything before marker 1
+cur, per = "before_first_marker (index build, warm-up and the timed headline loop)", OrderedDict()
+for r in rows:
+    n = r["Kernel_Name"]
+    if "phase_marker_kernel" in n:
+        pid = int(r["Grid_Size_X"]) // 64
+        cur = "phase_%d" % pid if pid < 60000 else None
+        continue
+    if cur is None:
+        continue
+    per.setdefault(cur, defaultdict(list))[short(n)[:100]].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+out["per_phase_kernel_avg_us"] = {p: {k: {"calls": len(v), "avg_us": sum(v) / len(v), "min_us": min(v)} for k, v in ks.items()
+                                      if any(t in k for t in ("count_", "locate", "localise", "scan_", "pack_"))} for p, ks in per.items()}
+try:
+    b = json.load(open(bench_json))
+    out["bench_line_of_this_run"] = {"value": b["value"], "ms_per_step": b["ms_per_step"], "roofline_kernel": b["roofline"]["kernel"],
+                                     "roofline_kernel_ms_hip_events": b["roofline"]["kernel_ms"]}
+    out["phase_order"] = "phase ids follow bench.py's order: unseeded, present, present_lf, ascii_pack_count, ascii_one_call, locate_count_lf, locate_scan, locate_walk, locate_dense, locate_count_sv, locate_sv, amino_random, amino_offsets_random, amino_present, amino_offsets_present"
+except (OSError, ValueError, KeyError):
+    pass
+print(json.dumps(out, indent=1))

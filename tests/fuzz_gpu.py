@@ -33,7 +33,7 @@ for trial in range(trials):
     oi = oracle_ffi.OracleIndex.from_text(text, alphabet, ratio, 0, st, hd)
     letters = np.frombuffer(b"ACGT" if alphabet == 0 else b"ACDEFGHIKLMNPQRSTVWY", np.uint8)
     mode = int(rng.integers(0, 3))  # 0 fixed length, 1 ragged, 2 ragged with ambiguity letters / lower case
-    nq = int(rng.choice([1, 70, 5000, 30000]))
+    nq = int(rng.choice([1, 70, 5000, 30000, 70000], p=[0.24, 0.24, 0.24, 0.2, 0.08]))  # 70000: above the host path's assumed-uniform threshold
     Lfix = int(rng.integers(1, min(120, n) + 1))
     if only_aa:
         mode, nq, Lfix = 0, int(rng.choice([5000, 12000])), int(rng.integers(6, 27))

@@ -78,6 +78,7 @@ def load_library():
     sig("awry_set_seed_kmer_len", i32, vp, i32)
     sig("awry_seed_kmer_len", i32, vp)
     sig("awry_debug_set_count_kernel", i32, i32)
+    sig("awry_debug_force_wide_rows", i32, i32)
     sig("awry_count_schedule", cp, vp, i32)
     sig("awry_num_devices", i32, vp)
     sig("awry_replica_device", i32, vp, i32)

@@ -182,6 +182,8 @@ struct Replica {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   DevBuf<uint64_t> blocks, sa_words, seq_starts;
   DevBuf<SeedEntry> seed;
+  DevBuf<SeedEntry64> seed64;  // wide-row replicas (bwt_len >= 2^32, or forced): 16-byte entries
+  bool wide = false;           // 64-bit rows: wide kernels, no 32-bit accelerators
   DevBuf<uint32_t> text4;                     // 4-bit text for seed-and-verify (device-only accelerator)
   DevBuf<uint8_t> text8;                      // the text as symbol indices, for the generic kernel's verify (any alphabet)
   DevBuf<uint32_t> dense_sa;                  // SA[j * dense_ratio] as u32 (device-only accelerator for locate)
@@ -215,7 +217,7 @@ struct Replica {
       for (auto& ls : lane_stream) if (ls) (void)hipStreamDestroy(ls);
       if (ev0) (void)hipEventDestroy(ev0);
       if (ev1) (void)hipEventDestroy(ev1);
-      blocks.reset(); sa_words.reset(); seq_starts.reset(); seed.reset(); dense_sa.reset(); text4.reset();
+      blocks.reset(); sa_words.reset(); seq_starts.reset(); seed.reset(); seed64.reset(); dense_sa.reset(); text4.reset();
       scratch.clear();
       sa_nblock.reset(); text8.reset();
     }
@@ -279,7 +281,11 @@ int count_kernel_mode(uint64_t bwt_len, int seed_k, bool seeded) {
   return 2;
 }
 
-bool narrow(const HostIndex& h) { return h.bwt_len < (1ull << 32) - 512; }
+// Rows fit 32 bits: the packed kernels, seed entries and accelerators are the 32-bit ones.  awry_debug_force_wide_rows(1)
+// makes replicas built afterwards take the wide-row (64-bit) kernels whatever their size -- how those kernels are tested,
+// since an index of 2^32 rows takes an hour of host SA-IS to build (the GPU builder stops below 2^32).
+std::atomic<int> g_force_wide{0};
+bool narrow(const HostIndex& h) { return h.bwt_len < (1ull << 32) - 512 && !g_force_wide.load(); }
 
 // HBM the accelerator policies may plan with on the current device: what is free now, capped by AWRY_HBM_BUDGET_GB (a
 // process that shares the GPU, or wants room for its own buffers, sets it; the seed table is sized to 70 % and the
@@ -296,7 +302,15 @@ bool hbm_budget(size_t* free_out) {
 }
 
 int default_seed_k(const HostIndex& h) {
-  if (!narrow(h)) return 0;
+  if (!narrow(h)) {  // wide rows: nucleotide only, 16-byte entries (+ 4 B scratch per entry while building)
+    if (h.alphabet != NUCLEOTIDE) return 0;
+    if (const char* e = getenv("AWRY_SEED_K")) return std::max(0, std::min(17, atoi(e)));
+    int k = std::min(17, (int)std::floor(std::log((double)h.bwt_len) / std::log(4.0)) + 2);
+    size_t free_b = 0;
+    if (hbm_budget(&free_b))
+      while (k > 1 && 20.0 * std::pow(4.0, k) > 0.7 * (double)free_b) k--;
+    return std::max(1, k);
+  }
   const bool nt = h.alphabet == NUCLEOTIDE;
   if (const char* e = getenv("AWRY_SEED_K")) return std::max(0, std::min(nt ? 17 : 7, atoi(e)));
   if (!nt) {  // amino: 20^k ~ 1..20 x bwt_len (Swiss-Prot 9e7 -> k = 7, 10 GB), same memory rule as below
@@ -327,7 +341,32 @@ void build_seed(awry_index* ix, Replica& r, int k) {
   r.dev.seed_k = 0;
   r.dev.seed_pos = 0;
   r.dev.ctx_extra = 0;
+  r.seed64.reset();
+  r.dev.seed64 = nullptr;
   if (k <= 0) return;
+  if (r.wide) {  // 64-bit rows: 16-byte entries, nucleotide only
+    require(ix->host.alphabet == NUCLEOTIDE, "a wide-row seed table needs a nucleotide index");
+    require(k <= 17, "seed k-mer length must be <= 17");
+    const uint64_t nfinal = 1ull << (2 * k);
+    DevBuf<SeedEntry64> a(nfinal), b(std::max<uint64_t>(4, nfinal / 4));
+    SeedEntry64* cur = ((k - 1) % 2 == 0) ? a.p : b.p;
+    hipLaunchKernelGGL(seed64_level1_kernel, dim3(1), dim3(256), 0, r.stream, r.dev, cur);
+    uint64_t nchild = 4;
+    for (int j = 2; j <= k; j++) {
+      SeedEntry64* nxt = ((k - j) % 2 == 0) ? a.p : b.p;
+      nchild *= 4;
+      hipLaunchKernelGGL(seed64_extend_kernel, dim3(grid_for(r, nchild * 4, 256)), dim3(256), 0, r.stream, r.dev, cur, nxt, nchild);
+      cur = nxt;
+    }
+    hipLaunchKernelGGL(seed64_finalize_kernel, dim3(grid_for(r, nfinal, 256)), dim3(256), 0, r.stream, r.dev, a.p, nfinal);
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipStreamSynchronize(r.stream));
+    r.seed64 = std::move(a);
+    r.seed_k = k;
+    r.dev.seed64 = r.seed64.p;
+    r.dev.seed_k = k;
+    return;
+  }
   require(narrow(ix->host), "seed table needs an index with bwt_len < 2^32");
   const bool nt = ix->host.alphabet == NUCLEOTIDE;
   const uint64_t sigma = nt ? 4 : AA_SEED_SIGMA;
@@ -368,6 +407,7 @@ void refresh_nblock(awry_index* ix, Replica& r);
 void sync_seed_mode(awry_index* ix, Replica& r) {
   const HostIndex& h = ix->host;
   static const bool off = getenv("AWRY_SEED_POS") && !strcmp(getenv("AWRY_SEED_POS"), "0");
+  if (r.wide) return;  // wide rows: no position seeds (32-bit structures)
   const bool nt = h.alphabet == NUCLEOTIDE;
   // nucleotide: text4 resident and the two-phase schedules are the policy; amino: text8 resident (its only consumer, the
   // generic kernel, then finishes singletons against the text)
@@ -418,7 +458,9 @@ std::unique_ptr<Replica> make_replica(awry_index* ix, int device) {
   if (!h.sa_words.empty()) HIP_CHECK(hipMemcpy(r->sa_words.p, h.sa_words.data(), h.sa_words.size() * 8, hipMemcpyHostToDevice));
   if (!h.seq_starts.empty())
     HIP_CHECK(hipMemcpy(r->seq_starts.p, h.seq_starts.data(), h.seq_starts.size() * 8, hipMemcpyHostToDevice));
+  r->wide = !narrow(h);
   DevIndex& d = r->dev;
+  d.seed64 = nullptr;
   d.blocks = r->blocks.p;
   d.sa_words = r->sa_words.p;
   d.seed = nullptr;
@@ -447,7 +489,7 @@ std::unique_ptr<Replica> make_replica(awry_index* ix, int device) {
     vreq = -1;
     const char* e = getenv("AWRY_VERIFY");
     size_t free_b = 0;
-    if (!(e && !strcmp(e, "0")) && narrow(h) && hbm_budget(&free_b) && (double)h.bwt_len * 7.0 < 0.5 * (double)free_b)
+    if (!(e && !strcmp(e, "0")) && !r->wide && narrow(h) && hbm_budget(&free_b) && (double)h.bwt_len * 7.0 < 0.5 * (double)free_b)
       vreq = e && atoi(e) > 0 ? atoi(e) : 2;
   }
   if (vreq >= 0) build_verify(ix, *r, vreq);
@@ -602,7 +644,7 @@ void build_dense_sa(awry_index* ix, Replica& r, int ratio) {
   r.dev.dense_sa = nullptr;
   r.dev.dense_ratio = 0;
   if (ratio <= 0) return;
-  require(ix->host.bwt_len < (1ull << 32), "a dense device SA needs bwt_len < 2^32");
+  require(!r.wide && ix->host.bwt_len < (1ull << 32), "a dense device SA needs an index with 32-bit rows (bwt_len < 2^32)");
   const uint64_t nentries = (ix->host.bwt_len + ratio - 1) / ratio;
   const uint64_t nsamples = (ix->host.bwt_len + ix->host.sa_ratio - 1) / ix->host.sa_ratio;  // one chain per file sample
   DevBuf<uint32_t> d(nentries);
@@ -622,7 +664,7 @@ void build_dense_sa(awry_index* ix, Replica& r, int ratio) {
 void refresh_nblock(awry_index* ix, Replica& r) {
   const HostIndex& h = ix->host;
   const uint64_t lo = h.alphabet == NUCLEOTIDE ? h.prefix_sums[4] : 0, hi = h.alphabet == NUCLEOTIDE ? h.prefix_sums[5] : 0;
-  const bool want = h.alphabet == NUCLEOTIDE && narrow(h) && r.dense_ratio != 1 && hi - lo >= 64;
+  const bool want = h.alphabet == NUCLEOTIDE && !r.wide && narrow(h) && r.dense_ratio != 1 && hi - lo >= 64;
   if (!want) {
     r.sa_nblock.reset();
     r.dev.sa_nblock = nullptr;
@@ -649,7 +691,7 @@ void build_verify(awry_index* ix, Replica& r, int after_steps) {
   r.dev.text8 = nullptr;
   r.dev.verify_after = 0;
   if (after_steps < 0) return;
-  require(narrow(ix->host), "seed-and-verify needs an index with bwt_len < 2^32");
+  require(!r.wide && narrow(ix->host), "seed-and-verify needs an index with bwt_len < 2^32");
   if (r.dense_ratio != 1) build_dense_sa(ix, r, 1);
   if (r.dense_ratio != 1 || !r.dense_sa.p) throw HipError("seed-and-verify: the ratio-1 dense SA is missing");
   const bool nt = ix->host.alphabet == NUCLEOTIDE;
@@ -686,9 +728,18 @@ Replica::SurvScratch* surv_scratch(Replica& r, hipStream_t s) {
 void launch_count_nt2_long(Replica& r, const uint64_t* d_words, uint64_t n, int L, uint64_t* d_counts, uint64_t* d_range_start,
                            bool use_seed, hipStream_t s, const uint32_t* d_lens = nullptr) {
   require(r.dev.alphabet == NUCLEOTIDE, "packed 2-bit queries need a nucleotide index");
-  require(r.dev.bwt_len < (1ull << 32) - 512, "the quad kernel needs bwt_len < 2^32");
   require(L >= 1 && L <= 1 << 20, "packed read length out of range");
   if (n == 0) return;
+  if (r.wide) {  // 64-bit rows
+    const bool sdw = use_seed && r.seed_k > 0 && r.dev.seed64 && (d_lens || r.seed_k <= L);
+    const dim3 gw(grid_for(r, n * 4, 256)), bw(256);
+#define AWRY_LAUNCH_WIDE(S, R) hipLaunchKernelGGL((count_nt2_wide_kernel<S, R>), gw, bw, 0, s, r.dev, d_words, n, L, d_counts, d_range_start, d_lens, (unsigned long long*)nullptr)
+    if (d_lens) { if (sdw) AWRY_LAUNCH_WIDE(true, true); else AWRY_LAUNCH_WIDE(false, true); }
+    else { if (sdw) AWRY_LAUNCH_WIDE(true, false); else AWRY_LAUNCH_WIDE(false, false); }
+#undef AWRY_LAUNCH_WIDE
+    HIP_CHECK(hipGetLastError());
+    return;
+  }
   const bool sd = use_seed && r.seed_k > 0 && (d_lens || r.seed_k <= L);  // ragged reads decide per read
   const bool vfy = r.dev.text4 && r.dev.dense_ratio == 1;
   const dim3 g(grid_for(r, n * 4, 256)), b(256);
@@ -732,9 +783,16 @@ void launch_count_nt2_long(Replica& r, const uint64_t* d_words, uint64_t n, int 
 void launch_count_nt2(Replica& r, const uint64_t* d_words, uint64_t n, int L, uint64_t* d_counts, bool use_seed, hipStream_t s,
                       unsigned long long* d_tally = nullptr) {
   require(r.dev.alphabet == NUCLEOTIDE, "packed 2-bit queries need a nucleotide index");
-  require(r.dev.bwt_len < (1ull << 32) - 512, "the quad kernel needs bwt_len < 2^32");
   require(L >= 1 && L <= 32, "packed k-mer length must be in 1..32");
   if (n == 0) return;
+  if (r.wide) {  // 64-bit rows: one word per k-mer is the W = 1 case of the wide kernel
+    const bool sdw = use_seed && r.seed_k > 0 && r.dev.seed64 && r.seed_k <= L;
+    const dim3 gw(grid_for(r, n * 4, 256)), bw(256);
+    if (sdw) hipLaunchKernelGGL((count_nt2_wide_kernel<true, false>), gw, bw, 0, s, r.dev, d_words, n, L, d_counts, (uint64_t*)nullptr, (const uint32_t*)nullptr, d_tally);
+    else hipLaunchKernelGGL((count_nt2_wide_kernel<false, false>), gw, bw, 0, s, r.dev, d_words, n, L, d_counts, (uint64_t*)nullptr, (const uint32_t*)nullptr, d_tally);
+    HIP_CHECK(hipGetLastError());
+    return;
+  }
   const bool seeded = use_seed && r.seed_k > 0 && r.seed_k <= L;
   const dim3 g(grid_for(r, n * 4, 256)), b(256);
   // AWRY_COUNT_KERNEL=chunk selects the LDS-staged variant (count_nt2_chunk_kernel).  Measured on MI355X it is
@@ -880,7 +938,7 @@ void launch_count_ascii_uniform(Replica& r, const uint8_t* d_q, uint64_t n, uint
   const bool two_phase = !off && r.dev.alphabet == AMINO && L >= (uint64_t)AA_KMER_MIN && L <= (uint64_t)AA_KMER_MAX && r.seed_k >= 1 &&
                          (uint64_t)r.seed_k <= L && n < (1ull << 32);
   Replica::SurvScratch* sc = surv_scratch(r, s);
-  if (r.dev.alphabet == NUCLEOTIDE && !d_ranges && r.dev.bwt_len < (1ull << 32) - 512 && L <= 4096 && n < (1ull << 32)) {
+  if (r.dev.alphabet == NUCLEOTIDE && !d_ranges && L <= 4096 && n < (1ull << 32)) {
     // the device half of the packed host path: pack 2 bits per letter, packed kernels, and the generic kernel over the
     // pack kernel's list for the queries with letters outside ACGT (it also writes their status)
     const uint64_t W = (L + 31) / 32;
@@ -1018,6 +1076,7 @@ void count_shard_hostpacked(Replica& r, const uint8_t* qbytes, const uint64_t* q
   auto now = [] { return std::chrono::steady_clock::now(); };
   auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
   double t_pack = 0, t_wait = 0, t_out = 0, t_bad = 0;
+  const bool narrow32 = r.dev.bwt_len < (1ull << 32);  // a count is at most bwt_len
   std::lock_guard<std::mutex> lane_lock(r.lane_mu);
   const auto t0 = now();
   PackedLane* lanes = r.lanes;
@@ -1028,7 +1087,8 @@ void count_shard_hostpacked(Replica& r, const uint8_t* qbytes, const uint64_t* q
     auto a = now();
     HIP_CHECK(hipEventSynchronize(ln.done));
     auto b = now();
-    pool_widen_u32(counts_out + ln.chunk_lo, ln.h_counts32.p, ln.chunk_hi - ln.chunk_lo);
+    if (narrow32) pool_widen_u32(counts_out + ln.chunk_lo, ln.h_counts32.p, ln.chunk_hi - ln.chunk_lo);
+    else pool_memcpy(counts_out + ln.chunk_lo, ln.h_words.p, (ln.chunk_hi - ln.chunk_lo) * 8);  // (a count may pass 2^32: 64-bit words, staged where the packed words were)
     if (trace) { t_wait += ms(a, b); t_out += ms(b, now()); }
     redone += ln.nbad;
     if (ln.nbad && ln.h_bad[1] != ~0ull) {  // the lowest query of the chunk that the reference leaves undefined
@@ -1112,9 +1172,13 @@ void count_shard_hostpacked(Replica& r, const uint8_t* qbytes, const uint64_t* q
       HIP_CHECK(hipGetLastError());
       HIP_CHECK(hipMemcpyAsync(ln.h_bad + 1, ln.bad.p + 1, 8, hipMemcpyDeviceToHost, ln.s));
     }
-    hipLaunchKernelGGL(narrow_counts_kernel, dim3(grid_for(r, n, 1024)), dim3(256), 0, ln.s, ln.counts.p, ln.counts32.p, n);
-    HIP_CHECK(hipGetLastError());
-    HIP_CHECK(hipMemcpyAsync(ln.h_counts32.p, ln.counts32.p, n * 4, hipMemcpyDeviceToHost, ln.s));
+    if (narrow32) {
+      hipLaunchKernelGGL(narrow_counts_kernel, dim3(grid_for(r, n, 1024)), dim3(256), 0, ln.s, ln.counts.p, ln.counts32.p, n);
+      HIP_CHECK(hipGetLastError());
+      HIP_CHECK(hipMemcpyAsync(ln.h_counts32.p, ln.counts32.p, n * 4, hipMemcpyDeviceToHost, ln.s));
+    } else {
+      HIP_CHECK(hipMemcpyAsync(ln.h_words.p, ln.counts.p, n * 8, hipMemcpyDeviceToHost, ln.s));
+    }
     HIP_CHECK(hipEventRecord(ln.done, ln.s));
     ln.busy = true;
     if (trace) { t_pack += ms(a, b); t_bad += ms(b, now()); }
@@ -1332,7 +1396,7 @@ void count_shard(Replica& r, const uint8_t* qbytes, const uint64_t* qoff, Shard 
   const auto t0 = std::chrono::steady_clock::now();
   static const bool dev_pack = getenv("AWRY_HOST_PACK") && !strcmp(getenv("AWRY_HOST_PACK"), "0");
   PackedPlan plan;
-  const bool packable = !no_fast && r.dev.alphabet == NUCLEOTIDE && r.dev.bwt_len < (1ull << 32) - 512;
+  const bool packable = !no_fast && r.dev.alphabet == NUCLEOTIDE;  // (wide-row replicas take the 64-bit packed kernels)
   if (packable && !dev_pack && sh.hi - sh.lo >= (1u << 16)) {
     // k-mer and read batches are nearly always of one length: assume the first query's, let the packer check the
     // offsets in the pass that reads the bytes anyway (a separate scan of 8 B per query costs 7 % of a 31-mer batch)
@@ -1766,7 +1830,7 @@ void locate_shard(Replica& r, const uint8_t* qbytes, const uint64_t* qoff, Shard
   out.nq = sh.hi - sh.lo;
   static const bool no_fast = getenv("AWRY_HOST_PATH") && !strcmp(getenv("AWRY_HOST_PATH"), "generic");
   PackedPlan plan;
-  if (!no_fast && r.dev.alphabet == NUCLEOTIDE && r.dev.bwt_len < (1ull << 32) - 512) plan = plan_packed(qoff, sh);
+  if (!no_fast && r.dev.alphabet == NUCLEOTIDE) plan = plan_packed(qoff, sh);
   if (plan.ok || (!no_fast && sh.hi - sh.lo >= 4096))
     locate_shard_packed(r, qbytes, qoff, sh, plan, want_gpos, out);
   else
@@ -2004,12 +2068,14 @@ int awry_set_seed_kmer_len(awry_index_t* idx, int k) {
 }
 
 int awry_debug_set_count_kernel(int mode) { g_count_kernel.store(mode); return AWRY_OK; }
+int awry_debug_force_wide_rows(int on) { g_force_wide.store(on ? 1 : 0); return AWRY_OK; }
 
 const char* awry_count_schedule(const awry_index_t* idx, int L) {
   static const char* names[] = {"count_nt2_quad_kernel", "count_nt2_chunk_kernel", "count_nt2_quad4_kernel",
                                 "count_nt2_probe_kernel+count_nt2_resume_kernel"};
   if (!idx || idx->reps.empty()) return "";
   const Replica& r = *idx->reps[0];
+  if (r.wide) return "count_nt2_wide_kernel";
   const bool seeded = r.seed_k > 0 && r.seed_k <= L;
   if (L > 32) {  // launch_count_nt2_long
     const int om = count_kernel_override();
@@ -2046,7 +2112,7 @@ int awry_count_packed_kmers(awry_index_t* idx, const uint64_t* words, uint64_t n
     require(L >= 1 && L <= 32, "packed k-mer length must be in 1..32");
     for_each_replica(idx, n, [&](Replica& r, Shard sh, int) {
       HIP_CHECK(hipSetDevice(r.device));
-      require(r.dev.alphabet == NUCLEOTIDE && r.dev.bwt_len < (1ull << 32) - 512, "packed k-mers need a nucleotide index with bwt_len < 2^32");
+      require(r.dev.alphabet == NUCLEOTIDE, "packed k-mers need a nucleotide index");
       if (sh.hi <= sh.lo) return;
       PackedPlan plan;
       plan.ok = true;

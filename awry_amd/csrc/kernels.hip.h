@@ -2479,4 +2479,153 @@ __global__ __launch_bounds__(256) void locate_walk_nt_lane_kernel(DevIndex ix, u
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Wide rows: nucleotide indexes of 2^32 rows or more (the reference is u64 throughout, src/search.rs:7).  The same quad
+// design as above with 64-bit rows and 16-byte seed entries (SeedEntry64); no verify accelerators (the dense SA and the
+// position seeds are 32-bit structures) -- every letter left of the seed window is an LF step.
+// ------------------------------------------------------------------------------------------------
+
+// sum over the 4 lanes of a quad of a 64-bit value
+__device__ __forceinline__ uint64_t quad_sum64(uint64_t v) {
+  v += __shfl_xor(v, 1, 64);
+  v += __shfl_xor(v, 2, 64);
+  return v;
+}
+__device__ __forceinline__ QuadBlock quad_load64(const uint64_t* __restrict__ blocks, uint64_t b, int l) {
+  const ulonglong2* p = reinterpret_cast<const ulonglong2*>(blocks + b * NT_BLOCK_WORDS);
+  QuadBlock q;
+  q.lo = p[l];
+  q.hi = p[4 + l];
+  return q;
+}
+__device__ __forceinline__ uint64_t quad_rank_part64(const QuadBlock& d, const NtXor& x, uint64_t row, uint32_t c, int l) {
+  const uint64_t pred = (d.lo.x ^ x.x0) & (d.lo.y ^ x.x1) & (d.hi.x ^ x.x2);
+  const uint64_t cnt = (uint64_t)__popcll(pred & slice_mask((int)(row & 255u) - 64 * l));
+  return cnt + ((uint32_t)l == c ? d.hi.y : 0ull);
+}
+// one backward-search step with letter c (src/fm_index.rs:559-582), 64-bit rows
+__device__ __forceinline__ void quad_step64(const uint64_t* __restrict__ blocks, uint64_t cl, uint64_t& sp, uint64_t& ep, uint32_t c, int l) {
+  const uint64_t r0 = sp - 1, r1 = ep;
+  const uint64_t b0 = r0 >> 8, b1 = r1 >> 8;
+  QuadBlock d0 = quad_load64(blocks, b0, l);
+  QuadBlock d1 = d0;
+  if (b1 != b0) d1 = quad_load64(blocks, b1, l);
+  const NtXor x = nt_xor_of_letter(c);
+  const uint64_t v0 = quad_sum64(quad_rank_part64(d0, x, r0, c, l));
+  const uint64_t v1 = quad_sum64(quad_rank_part64(d1, x, r1, c, l));
+  sp = cl + v0;
+  ep = cl + v1 - 1;
+}
+
+__global__ __launch_bounds__(256) void seed64_level1_kernel(DevIndex ix, SeedEntry64* __restrict__ out) {
+  if (blockIdx.x == 0 && threadIdx.x < 4) {
+    const int idx = nt_index_of_letter((int)threadIdx.x);
+    const uint64_t s = ix.prefix_sums[idx], e = ix.prefix_sums[idx + 1];
+    out[threadIdx.x] = SeedEntry64{s, e - s};
+  }
+}
+__global__ __launch_bounds__(256) void seed64_extend_kernel(DevIndex ix, const SeedEntry64* __restrict__ parent,
+                                                            SeedEntry64* __restrict__ child, uint64_t nchild) {
+  const int l = threadIdx.x & 3;
+  const uint64_t nquads = ((uint64_t)gridDim.x * blockDim.x) >> 2;
+  const uint64_t cA = ix.prefix_sums[1], cC = ix.prefix_sums[2], cG = ix.prefix_sums[3], cT = ix.prefix_sums[5];
+  for (uint64_t o = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 2; o < nchild; o += nquads) {
+    const SeedEntry64 p = parent[o >> 2];
+    SeedEntry64 r{p.sp, 0};
+    if (p.cnt) {
+      const uint32_t c = (uint32_t)(o & 3);
+      const uint64_t cl = c == 0 ? cA : (c == 1 ? cC : (c == 2 ? cG : cT));
+      uint64_t sp = p.sp, ep = p.sp + p.cnt - 1;
+      quad_step64(ix.blocks, cl, sp, ep, c, l);
+      r.sp = sp;
+      r.cnt = sp > ep ? 0ull : ep - sp + 1ull;
+    }
+    if (l == 0) child[o] = r;
+  }
+}
+__global__ __launch_bounds__(256) void seed64_finalize_kernel(DevIndex ix, SeedEntry64* __restrict__ table, uint64_t nentries) {
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t o = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; o < nentries; o += stride) {
+    SeedEntry64 e = table[o];
+    if (e.cnt != 1ull) continue;
+    e.cnt = 1ull | ((uint64_t)symbol_at<NUCLEOTIDE>(ix, e.sp) << 61);
+    table[o] = e;
+  }
+}
+
+// Packed reads / k-mers of any length on a wide-row index: W = ceil(L / 32) words per query (L <= 32: one word, the
+// k-mer layout), one query per quad, strided.  RAGGED: read q has lens[q] letters.  Counts, and (optional) the first row
+// of each range for the locate pass (RS_PLAIN words).  tally (nullable): [0] probes, [1] steps, [2] blocks ranked.
+template <bool USE_SEED, bool RAGGED>
+__global__ __launch_bounds__(256) void count_nt2_wide_kernel(DevIndex ix, const uint64_t* __restrict__ queries, uint64_t n, int L,
+                                                             uint64_t* __restrict__ counts, uint64_t* __restrict__ range_start,
+                                                             const uint32_t* __restrict__ lens, unsigned long long* __restrict__ tally) {
+  const int l = threadIdx.x & 3;
+  const uint64_t nquads = ((uint64_t)gridDim.x * blockDim.x) >> 2;
+  uint64_t q = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 2;
+  const uint64_t* __restrict__ blocks = ix.blocks;
+  const SeedEntry64* __restrict__ seed = ix.seed64;
+  const int k = USE_SEED ? ix.seed_k : 1, W = (L + 31) / 32;
+  const uint64_t cA = ix.prefix_sums[1], cC = ix.prefix_sums[2], cG = ix.prefix_sums[3], cN = ix.prefix_sums[4], cT = ix.prefix_sums[5],
+                 cEnd = ix.prefix_sums[6];
+  bool have = q < n, fresh = true;
+  uint64_t w = 0, sp = 1, ep = 0;
+  int i = 0;
+  unsigned long long t_probe = 0, t_step = 0, t_blk = 0;
+  while (__any(have)) {
+    if (have) {
+      const uint64_t* qw = queries + q * W;
+      if (fresh) {
+        const int Lq = RAGGED ? (int)lens[q] : L;
+        const bool seeded = USE_SEED && Lq >= k;
+        const int first = seeded ? Lq - k : 0;  // letters first .. Lq-1 form the seed window (leftmost letter least significant)
+        if (seeded) {
+          const int a = first >> 5, sh = 2 * (first & 31);
+          uint64_t win = qw[a] >> sh;
+          if (sh && a + 1 < W) win |= qw[a + 1] << (64 - sh);
+          const SeedEntry64 e = seed[win & ((1ull << (2 * k)) - 1)];
+          const uint64_t scnt = seed64_cnt(e);
+          sp = scnt ? e.sp : 1ull;
+          ep = scnt ? e.sp + scnt - 1ull : 0ull;
+          i = first;
+          if (scnt == 1ull && i > 0) {  // singleton: it survives the next step only if BWT[sp] is the next letter
+            const uint32_t nc = (uint32_t)(qw[(i - 1) >> 5] >> (2 * ((i - 1) & 31))) & 3u;
+            if (seed64_sym(e) != (int)(nc == 3u ? 5u : nc + 1u)) { sp = 1ull; ep = 0ull; }
+          }
+          t_probe++;
+        } else {
+          const uint32_t c = (uint32_t)(qw[(Lq - 1) >> 5] >> (2 * ((Lq - 1) & 31))) & 3u;  // SearchRange::new(last letter)
+          sp = c == 0 ? cA : (c == 1 ? cC : (c == 2 ? cG : cT));
+          ep = (c == 0 ? cC : (c == 1 ? cG : (c == 2 ? cN : cEnd))) - 1;
+          i = Lq - 1;
+        }
+        w = i > 0 ? qw[(i - 1) >> 5] : 0;
+        fresh = false;
+      } else {
+        i--;
+        const uint32_t c = (uint32_t)(w >> (2 * (i & 31))) & 3u;
+        const uint64_t cl = c == 0 ? cA : (c == 1 ? cC : (c == 2 ? cG : cT));
+        t_step++;
+        t_blk += ((sp - 1) >> 8) == (ep >> 8) ? 1u : 2u;
+        quad_step64(blocks, cl, sp, ep, c, l);
+        if ((i & 31) == 0 && i > 0) w = qw[(i - 1) >> 5];
+      }
+      if (sp > ep || i == 0) {
+        if (l == 0) {
+          counts[q] = sp > ep ? 0ull : ep - sp + 1ull;
+          if (range_start) range_start[q] = (RS_PLAIN << RS_MODE_SHIFT) | sp;
+        }
+        q += nquads;
+        have = q < n;
+        fresh = true;
+      }
+    }
+  }
+  if (tally && l == 0) {
+    atomicAdd(&tally[0], t_probe);
+    atomicAdd(&tally[1], t_step);
+    atomicAdd(&tally[2], t_blk);
+  }
+}
+
 }  // namespace awry

@@ -89,6 +89,14 @@ AWRY_HD uint64_t seed_full_ctx(SeedEntry e, int extra) {
 }
 AWRY_HD int seed_sym(SeedEntry e) { return (int)(e.cnt >> 29); }
 
+// Seed entry of an index with 2^32 rows or more ("wide rows": the packed kernels then carry 64-bit rows): the exact range
+// of a k-mer as (start row, count); final-level entries of singleton ranges also hold the symbol index stored in the BWT
+// at that row in bits 61..63 of cnt.  16 bytes, so the table's k is one less than a 32-bit index of the same HBM would get.
+struct SeedEntry64 { uint64_t sp, cnt; };
+constexpr uint64_t SEED64_CNT_MASK = (1ull << 61) - 1;
+AWRY_HD uint64_t seed64_cnt(SeedEntry64 e) { return e.cnt & SEED64_CNT_MASK; }
+AWRY_HD int seed64_sym(SeedEntry64 e) { return (int)(e.cnt >> 61); }
+
 // Amino seed entries (final level).  Plain: count in bits 0..25 (saturating at AA_SEED_CNT_SAT = "at least this many:
 // ignore the table"), and for singletons the 5-bit symbol index of BWT[sp] -- the residue in front of the one occurrence
 // -- in bits 27..31.  Bit 26 (AA_SEED_SPECIAL) marks the two encodings that let the ENTRY decide most k-mer queries:
@@ -122,7 +130,8 @@ AWRY_HD int aa_letter_of_index(int idx) { return idx >= 1 && idx <= 19 ? idx - 1
 struct DevIndex {
   const uint64_t* blocks;     // nblocks * block_words(alphabet), 128-B aligned
   const uint64_t* sa_words;   // bit-packed sampled SA, src/compressed_suffix_array.rs:51-64
-  const SeedEntry* seed;      // sigma^seed_k entries or nullptr
+  const SeedEntry* seed;      // sigma^seed_k entries or nullptr (indexes below 2^32 rows)
+  const SeedEntry64* seed64;  // 4^seed_k entries of a wide-row nucleotide index, or nullptr
   const uint64_t* seq_starts; // nseq record start offsets
   uint64_t nblocks, bwt_len, sentinel_row, nseq;
   uint64_t prefix_sums[24];   // C[i], src/fm_index.rs:233-240

@@ -85,6 +85,10 @@ int awry_seed_kmer_len(const awry_index_t *idx);
 /* A/B switch for the packed-k-mer count kernel (process-wide; -1 policy, 0 strided quads, 1 LDS-staged chunks,
  * 2 groups of four queries per quad, 3 two-phase probe + resume).  All variants return identical counts. */
 int awry_debug_set_count_kernel(int mode);
+/* Indexes of 2^32 rows or more take "wide-row" packed kernels (64-bit rows, 16-byte seed entries, no 32-bit accelerators;
+ * the reference is u64 throughout, src/search.rs:7).  on != 0 makes replicas placed AFTERWARDS (awry_set_devices) take
+ * those kernels whatever the index size -- for tests: a real index of that size takes an hour of host SA-IS to build. */
+int awry_debug_force_wide_rows(int on);
 /* device pointer of replica `slot`'s dense SA (u32 SA[j * ratio]) or NULL -- for tests that dump it */
 const void *awry_debug_dense_sa(const awry_index_t *idx, int slot);
 /* name(s) of the kernel(s) awry_dev_count_nt2 launches for k-mers of length L on replica 0 (for profiling reports) */

@@ -1295,3 +1295,56 @@ def test_amino_kmer_schedule_with_unequal_lengths(oracle, lo, hi):
     with pytest.raises(AwryError) as e:
         ix.parallel_count_csr(bad, qo)
     assert e.value.code == ERR_INVALID_QUERY and "query 1234" in str(e.value)
+
+
+def test_wide_row_kernels(oracle):
+    """indexes of 2^32 rows or more take packed kernels with 64-bit rows and 16-byte seed entries (the reference is u64
+    throughout, src/search.rs:7).  Such an index cannot be built in a test (an hour of host SA-IS), so the kernels are
+    forced onto small ones (awry_debug_force_wide_rows) and must give the oracle's counts and locations: k-mers and reads of
+    equal and unequal lengths, letters outside ACGT, with several seed lengths, device-resident and through the host paths"""
+    import awry_amd
+    L_ = awry_amd.load_library()
+    text, st, hd = repeat_text(33)
+    oi = oracle.OracleIndex.from_text(text, 0, 8, 0, st, hd)
+    L_.awry_debug_force_wide_rows(1)
+    try:
+        ix = gpu_index(text, 0, 8, 0, st, hd)
+    finally:
+        L_.awry_debug_force_wide_rows(0)
+    assert ix.count_schedule(31) == "count_nt2_wide_kernel" and not ix.verify_enabled() and ix.seed_kmer_len() >= 1
+    rng = np.random.default_rng(44)
+    for k in (-1, 0, 1, 5, 9):
+        ix.set_seed_kmer_len(k)
+        for L in (1, 7, 31, 32, 33, 64, 101, 150):
+            q2d = np.concatenate([synth.sampled_queries(text, 3000, L, L), synth.random_queries(1500, L, 0, L + 1)])
+            qb, qo = synth.fixed_to_csr(q2d)
+            want = oi.parallel_locate(qb, qo, 4)[:3]
+            if L <= 32:
+                assert np.array_equal(ix.count_kmers_nt2(q2d, True), np.diff(want[0])), (k, L)
+                assert np.array_equal(ix.count_kmers_nt2(q2d, False), np.diff(want[0])), (k, L)
+            off, g, p = ix.locate_reads_nt2(q2d)
+            assert np.array_equal(off, want[0]) and np.array_equal(g, want[1]) and np.array_equal(p, want[2]), (k, L)
+            if k in (-1, 5):
+                assert np.array_equal(ix.parallel_count_csr(qb, qo), np.diff(want[0])), (k, L)
+                got = ix.parallel_locate_csr(qb, qo)
+                assert all(np.array_equal(x, y) for x, y in zip(got, want)), (k, L)
+    # unequal lengths and letters outside ACGT through the host paths (host packer, compact redo, ragged wide kernel)
+    ix.set_seed_kmer_len(-1)
+    nq = 70000
+    lens = rng.integers(1, 60, size=nq)
+    qo = np.zeros(nq + 1, dtype=np.uint64)
+    qo[1:] = np.cumsum(lens)
+    starts = rng.integers(0, len(text) - 70, size=nq)
+    idx = np.repeat(starts, lens) + (np.arange(int(qo[-1])) - np.repeat(qo[:-1].astype(np.int64), lens))
+    qb = text[idx].copy()
+    rmask = np.repeat(rng.random(nq) < 0.3, lens)
+    qb[rmask] = synth.NT[rng.integers(0, 4, size=int(rmask.sum()))]
+    other = rng.random(len(qb)) < 0.002
+    qb[other] = np.frombuffer(b"NRYu", np.uint8)[rng.integers(0, 4, size=int(other.sum()))]
+    qb[qb == ord("$")] = ord("A")
+    want = oi.parallel_locate(qb, qo, 4)[:3]
+    assert np.array_equal(ix.parallel_count_csr(qb, qo), np.diff(want[0]))
+    got = ix.parallel_locate_csr(qb, qo)
+    assert all(np.array_equal(x, y) for x, y in zip(got, want))
+    with pytest.raises(AwryError):
+        ix.set_verify(2)  # the verify accelerators are 32-bit structures

@@ -200,6 +200,33 @@ inline uint64_t pack32(const uint8_t* p, int m, bool* ok) {
   return m >= 32 ? w : (w & ((1ull << (2 * m)) - 1));
 }
 
+// Two k-mers per step with AVX-512 (BW + VL; Zen 4 / Zen 5 and recent Xeons): the 32 bytes at p0 and at p1 side by side in
+// one register, the same table lookups and multiply-adds at twice the width, the four result dwords compacted into two
+// consecutive 64-bit words.  Bit i of the returned mask is set when byte i (0..31: first k-mer, 32..63: second) is valid.
+__attribute__((target("avx512f,avx512bw,avx512vl,avx512dq"))) inline uint64_t pack32x2_avx512(const uint8_t* p0, const uint8_t* p1, int m,
+                                                                                             uint64_t* out2) {
+  const __m512i x = _mm512_inserti64x4(_mm512_castsi256_si512(_mm256_loadu_si256(reinterpret_cast<const __m256i*>(p0))),
+                                       _mm256_loadu_si256(reinterpret_cast<const __m256i*>(p1)), 1);
+  const __m512i c = _mm512_and_si512(x, _mm512_set1_epi8((char)0xDF));
+  const __m512i letter = _mm512_broadcast_i32x4(_mm_setr_epi8(-1, 'A', -1, 'C', 'T', -1, -1, 'G', -1, -1, -1, -1, -1, -1, -1, -1));
+  const __m512i code = _mm512_broadcast_i32x4(_mm_setr_epi8(0, 0, 0, 1, 3, 0, 0, 2, 0, 0, 0, 0, 0, 0, 0, 0));
+  const uint64_t valid = _mm512_cmpeq_epi8_mask(_mm512_shuffle_epi8(letter, c), c);
+  const __m512i y = _mm512_shuffle_epi8(code, c);
+  const __m512i t = _mm512_maddubs_epi16(y, _mm512_set1_epi16(0x0401));
+  const __m512i u = _mm512_madd_epi16(t, _mm512_set1_epi32(0x00100001));
+  const __m512i s = _mm512_shuffle_epi8(u, _mm512_broadcast_i32x4(_mm_setr_epi8(0, 4, 8, 12, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1)));
+  // dword 0 of each 128-bit lane -> dwords 0..3: first k-mer = lanes 0, 1, second = lanes 2, 3
+  const __m512i g = _mm512_permutexvar_epi32(_mm512_setr_epi32(0, 4, 8, 12, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0), s);
+  __m128i w = _mm512_castsi512_si128(g);
+  if (m < 32) w = _mm_and_si128(w, _mm_set1_epi64x((long long)((1ull << (2 * m)) - 1)));
+  if ((reinterpret_cast<uintptr_t>(out2) & 15) == 0) _mm_stream_si128(reinterpret_cast<__m128i*>(out2), w);
+  else { _mm_stream_si64(reinterpret_cast<long long*>(out2), _mm_cvtsi128_si64(w)); _mm_stream_si64(reinterpret_cast<long long*>(out2 + 1), _mm_extract_epi64(w, 1)); }
+  return valid;
+}
+
+static const bool g_have_avx512 = __builtin_cpu_supports("avx512bw") && __builtin_cpu_supports("avx512vl") && __builtin_cpu_supports("avx512dq") &&
+                                  !(getenv("AWRY_HOST_AVX512") && !strcmp(getenv("AWRY_HOST_AVX512"), "0"));
+
 // one query of `len` letters at p -> W words; returns false when it holds a byte outside ACGTacgt
 inline bool pack_query(const uint8_t* p, uint64_t len, const uint8_t* end, uint64_t* out, uint64_t W) {
   bool ok = true;
@@ -246,7 +273,19 @@ bool pack_nt2_host(const uint8_t* ascii, const uint8_t* ascii_end, const uint64_
     if (!off && L <= 32) {  // k-mers: one load, one word per query
       const uint8_t* p = ascii + a * L;
       const int m = (int)L;
-      for (uint64_t q = a; q < b; q++, p += L) {
+      uint64_t q = a;
+      if (g_have_avx512) {  // two k-mers per step
+        const uint64_t need1 = m >= 32 ? 0xFFFFFFFFull : ((1ull << m) - 1), need = need1 | (need1 << 32);
+        for (; q + 2 <= b && p + L + 32 <= ascii_end; q += 2, p += 2 * L) {
+          _mm_prefetch(reinterpret_cast<const char*>(p + 1024), _MM_HINT_T0);
+          const uint64_t valid = pack32x2_avx512(p, p + L, m, words + q);
+          if ((valid & need) != need) {
+            if ((valid & need1) != need1) { local[nl++] = (uint32_t)q; if (nl == 64) flush(); }
+            if (((valid >> 32) & need1) != need1) { local[nl++] = (uint32_t)(q + 1); if (nl == 64) flush(); }
+          }
+        }
+      }
+      for (; q < b; q++, p += L) {
         _mm_prefetch(reinterpret_cast<const char*>(p + 1024), _MM_HINT_T0);
         bool ok = true;
         if (p + 32 <= ascii_end) _mm_stream_si64(reinterpret_cast<long long*>(words + q), (long long)pack32(p, m, &ok));  // written once, read by the DMA engine

@@ -41,6 +41,14 @@
 
 namespace awry {
 
+// A seed-table probe reads 8 bytes of a line nobody will touch again (the table is 10..140 GB and the probes are random):
+// loaded non-temporally, so that the line does not displace the streams that do have locality (query words, counts,
+// survivor lists) from L2 / Infinity Cache.  Measured on the headline batch: 33.5 -> 35.9 G queries/s.
+__device__ __forceinline__ SeedEntry seed_probe(const SeedEntry* __restrict__ p) {
+  const unsigned long long raw = __builtin_nontemporal_load(reinterpret_cast<const unsigned long long*>(p));
+  return SeedEntry{(uint32_t)raw, (uint32_t)(raw >> 32)};
+}
+
 // ------------------------------------------------------------------------------------------------
 // scalar helpers (one lane does a whole rank)
 // ------------------------------------------------------------------------------------------------
@@ -563,7 +571,7 @@ __global__ __launch_bounds__(256) void count_aa_kmer_probe_kernel(DevIndex ix, c
       i2[h] = word(c2[h], 16);
       flags[h] = fl;
       ev[h] = SeedEntry{1u, 0u};
-      if (qv[h] < n && !fl) ev[h] = seed[slot];
+      if (qv[h] < n && !fl) ev[h] = seed_probe(seed + slot);
       if (ql.tally) { const uint64_t pm = __ballot(qv[h] < n && !fl); if (lane == 0) tally_add(ql.tally, 0, (unsigned long long)__popcll(pm)); }
     }
     bool listed[NQ], vfy[NQ], multi[NQ];
@@ -1237,7 +1245,7 @@ __global__ __launch_bounds__(256) void count_nt2_probe_kernel(DevIndex ix, const
 #pragma unroll
     for (int h = 0; h < NQ; h++) {
       ev[h] = SeedEntry{1u, 0u};
-      if (qv[h] < n) ev[h] = seed[(wv[h] >> kshift) & kmask];
+      if (qv[h] < n) ev[h] = seed_probe(seed + ((wv[h] >> kshift) & kmask));
     }
 #pragma unroll
     for (int h = 0; h < NQ; h++) {
@@ -1987,7 +1995,7 @@ __global__ __launch_bounds__(256) void count_nt2_reads_probe_kernel(DevIndex ix,
 #pragma unroll
     for (int h = 0; h < NQ; h++) {
       ev[h] = SeedEntry{1u, 0u};
-      if (probe[h]) ev[h] = seed[win[h] & kmask];
+      if (probe[h]) ev[h] = seed_probe(seed + (win[h] & kmask));
     }
 #pragma unroll
     for (int h = 0; h < NQ; h++) {

@@ -303,7 +303,7 @@ __global__ __launch_bounds__(256) void count_scalar_kernel(DevIndex ix, const ui
           sidx = sidx * AA_SEED_SIGMA + (uint64_t)(letter < 0 ? 0 : letter);
         }
         if (std20) {
-          const SeedEntry se = ix.seed[sidx];
+          const SeedEntry se = seed_probe(ix.seed + sidx);
           tally_add(ql.tally, 0, 1);
           const uint32_t scnt = aa_seed_cnt(se);
           // BWT[row] is not the next residue / the next residue does not occur in the BWT over the entry's 2..4 rows
@@ -339,7 +339,7 @@ __global__ __launch_bounds__(256) void count_scalar_kernel(DevIndex ix, const ui
           sidx |= (uint64_t)(letter & 3) << (2 * j);  // leftmost letter of the window least significant
         }
         if (acgt) {
-          const SeedEntry se = ix.seed[sidx];
+          const SeedEntry se = seed_probe(ix.seed + sidx);
           tally_add(ql.tally, 0, 1);
           const uint32_t scnt = seed_cnt(se);
           const bool wrong_sym = scnt == 1 && e - k > b && seed_sym(se) != (int)lut[ascii[e - k - 1]];  // BWT[row] is not the next symbol
@@ -2104,7 +2104,11 @@ __device__ __forceinline__ bool row_is_sampled(const DevIndex& ix, const uint32_
   return ratio_divides(dense ? (uint64_t)dense_ratio : ix.sa_ratio, row);
 }
 __device__ __forceinline__ uint64_t row_sample(const DevIndex& ix, const uint32_t* dense, uint32_t dense_ratio, uint64_t row) {
+#if defined(AWRY_NT_DENSE)
+  return dense ? (uint64_t)__builtin_nontemporal_load(dense + ratio_quotient(dense_ratio, row)) : sa_sample(ix, ratio_quotient(ix.sa_ratio, row));
+#else
   return dense ? (uint64_t)dense[ratio_quotient(dense_ratio, row)] : sa_sample(ix, ratio_quotient(ix.sa_ratio, row));
+#endif
 }
 // (sample + steps) % bwt_len of src/fm_index.rs:534; sample < bwt_len and a walk is shorter than the text
 __device__ __forceinline__ uint64_t walked_position(uint64_t sample, uint64_t steps, uint64_t bwt_len) {

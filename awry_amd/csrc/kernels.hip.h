@@ -1960,7 +1960,21 @@ __global__ __launch_bounds__(256) void count_nt2_reads_probe_kernel(DevIndex ix,
         const uint32_t p = c2 ? ix.dense_sa[sp[h] + c2] : vp[h];
         uint32_t bad = p >= (uint32_t)i0 ? 0u : 1u;  // else the suffix starts too close to the text's beginning
         const uint64_t g = (uint64_t)p - (uint64_t)i0;
+#if defined(AWRY_SV_BATCH)
+        // the first four 32-symbol windows (reads of up to 128 + k letters: all of them) are fetched together and then
+        // compared: one round trip for a read that matches, where the early-exit loop below took one per window
+        if (!bad) {
+          TextWin tw[4];
+#pragma unroll
+          for (int c = 0; c < 4; c++) tw[c] = text_window_load(ix.text4, g + 32ull * c, c < nchunks ? i0 - 32 * c : 0);
+#pragma unroll
+          for (int c = 0; c < 4; c++)
+            if (c < nchunks) bad |= text_window_differs(tw[c], qw[c]);
+        }
+        for (int c = 4; c < nchunks && !bad; c++) bad = verify_part(ix.text4, g, i0, c >> 2, c & 3, qw[c]);
+#else
         for (int c = 0; c < nchunks && !bad; c++) bad = verify_part(ix.text4, g, i0, c >> 2, c & 3, qw[c]);
+#endif
         if (!bad) { mask |= 1u << c2; g1 = g; }
       }
       if (nc[h] == 1u && mask) settle(q[h], 1, (RS_SINGLE << RS_MODE_SHIFT) | g1);
@@ -2104,11 +2118,7 @@ __device__ __forceinline__ bool row_is_sampled(const DevIndex& ix, const uint32_
   return ratio_divides(dense ? (uint64_t)dense_ratio : ix.sa_ratio, row);
 }
 __device__ __forceinline__ uint64_t row_sample(const DevIndex& ix, const uint32_t* dense, uint32_t dense_ratio, uint64_t row) {
-#if defined(AWRY_NT_DENSE)
-  return dense ? (uint64_t)__builtin_nontemporal_load(dense + ratio_quotient(dense_ratio, row)) : sa_sample(ix, ratio_quotient(ix.sa_ratio, row));
-#else
   return dense ? (uint64_t)dense[ratio_quotient(dense_ratio, row)] : sa_sample(ix, ratio_quotient(ix.sa_ratio, row));
-#endif
 }
 // (sample + steps) % bwt_len of src/fm_index.rs:534; sample < bwt_len and a walk is shorter than the text
 __device__ __forceinline__ uint64_t walked_position(uint64_t sample, uint64_t steps, uint64_t bwt_len) {

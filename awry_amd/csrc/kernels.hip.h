@@ -1960,21 +1960,7 @@ __global__ __launch_bounds__(256) void count_nt2_reads_probe_kernel(DevIndex ix,
         const uint32_t p = c2 ? ix.dense_sa[sp[h] + c2] : vp[h];
         uint32_t bad = p >= (uint32_t)i0 ? 0u : 1u;  // else the suffix starts too close to the text's beginning
         const uint64_t g = (uint64_t)p - (uint64_t)i0;
-#if defined(AWRY_SV_BATCH)
-        // the first four 32-symbol windows (reads of up to 128 + k letters: all of them) are fetched together and then
-        // compared: one round trip for a read that matches, where the early-exit loop below took one per window
-        if (!bad) {
-          TextWin tw[4];
-#pragma unroll
-          for (int c = 0; c < 4; c++) tw[c] = text_window_load(ix.text4, g + 32ull * c, c < nchunks ? i0 - 32 * c : 0);
-#pragma unroll
-          for (int c = 0; c < 4; c++)
-            if (c < nchunks) bad |= text_window_differs(tw[c], qw[c]);
-        }
-        for (int c = 4; c < nchunks && !bad; c++) bad = verify_part(ix.text4, g, i0, c >> 2, c & 3, qw[c]);
-#else
         for (int c = 0; c < nchunks && !bad; c++) bad = verify_part(ix.text4, g, i0, c >> 2, c & 3, qw[c]);
-#endif
         if (!bad) { mask |= 1u << c2; g1 = g; }
       }
       if (nc[h] == 1u && mask) settle(q[h], 1, (RS_SINGLE << RS_MODE_SHIFT) | g1);

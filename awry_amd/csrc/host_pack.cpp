@@ -2,6 +2,7 @@
 #include "host_pack.h"
 
 #include <immintrin.h>
+#include <pthread.h>
 #include <sched.h>
 
 #include <algorithm>
@@ -93,12 +94,17 @@ struct HostPool::Impl {
   }
 };
 
+// a forked child inherits the pool object but none of its threads: it runs its jobs inline
+static std::atomic<bool> g_pool_forked{false};
+
 HostPool::HostPool() : impl_(new Impl) {
   const unsigned t = effective_cpus();
   for (unsigned i = 1; i < t; i++) impl_->workers.emplace_back([this] { impl_->worker(); });
+  (void)pthread_atfork(nullptr, nullptr, [] { g_pool_forked.store(true); });
 }
 
 HostPool::~HostPool() {
+  if (g_pool_forked.load()) return;  // (the threads belong to the parent)
   {
     std::lock_guard<std::mutex> lk(impl_->mu);
     impl_->stop = true;
@@ -118,7 +124,7 @@ unsigned HostPool::threads() const { return (unsigned)impl_->workers.size() + 1;
 void HostPool::run(uint64_t n, const std::function<void(uint64_t)>& fn) {
   if (n == 0) return;
   Impl& p = *impl_;
-  if (n == 1 || p.workers.empty()) {
+  if (n == 1 || p.workers.empty() || g_pool_forked.load(std::memory_order_relaxed)) {
     for (uint64_t i = 0; i < n; i++) fn(i);
     return;
   }

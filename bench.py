@@ -619,7 +619,13 @@ def main():
     if args.text_len:
         n_text = args.text_len
     L, nq, K, W = args.qlen, args.queries, args.steps, args.warmup
-    shm = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else "/tmp"
+    shm = "/tmp"  # scratch for the index / text handed to the other ranks and to the counter passes: RAM-backed when there is room
+    try:
+        st = os.statvfs("/dev/shm")
+        if os.access("/dev/shm", os.W_OK) and st.f_bavail * st.f_frsize > 3 * n_text + (4 << 30):
+            shm = "/dev/shm"
+    except OSError:
+        pass
     tmpdir = tempfile.mkdtemp(prefix="awry_bench_", dir=shm) if rank == 0 else None
     index_path = None
     want_pmc = not args.no_pmc and world == 1

@@ -1042,7 +1042,7 @@ def test_host_packed_boundary_details(oracle):
     oi = oracle.OracleIndex.from_text(text, 0, 8, 0, st, hd)
     rng = np.random.default_rng(5)
     for L in (31, 75):
-        nq = 2_600_000 if L == 31 else 1_300_000
+        nq = 1_300_000 if L == 31 else 300_000  # (L = 31: more than one full-size chunk of the host lanes)
         q2d = synth.sampled_queries(text, nq, L, 100 + L, skip_amb=False)
         q2d[q2d == ord("$")] = ord("A")
         rnd = rng.random(nq) < 0.3
@@ -1313,10 +1313,10 @@ def test_wide_row_kernels(oracle):
         L_.awry_debug_force_wide_rows(0)
     assert ix.count_schedule(31) == "count_nt2_wide_kernel" and not ix.verify_enabled() and ix.seed_kmer_len() >= 1
     rng = np.random.default_rng(44)
-    for k in (-1, 0, 1, 5, 9):
+    for k in (-1, 0, 1, 5):
         ix.set_seed_kmer_len(k)
-        for L in (1, 7, 31, 32, 33, 64, 101, 150):
-            q2d = np.concatenate([synth.sampled_queries(text, 3000, L, L), synth.random_queries(1500, L, 0, L + 1)])
+        for L in (1, 7, 31, 32, 33, 101, 150):
+            q2d = np.concatenate([synth.sampled_queries(text, 1500, L, L), synth.random_queries(800, L, 0, L + 1)])
             qb, qo = synth.fixed_to_csr(q2d)
             want = oi.parallel_locate(qb, qo, 4)[:3]
             if L <= 32:
@@ -1324,7 +1324,7 @@ def test_wide_row_kernels(oracle):
                 assert np.array_equal(ix.count_kmers_nt2(q2d, False), np.diff(want[0])), (k, L)
             off, g, p = ix.locate_reads_nt2(q2d)
             assert np.array_equal(off, want[0]) and np.array_equal(g, want[1]) and np.array_equal(p, want[2]), (k, L)
-            if k in (-1, 5):
+            if k == -1:
                 assert np.array_equal(ix.parallel_count_csr(qb, qo), np.diff(want[0])), (k, L)
                 got = ix.parallel_locate_csr(qb, qo)
                 assert all(np.array_equal(x, y) for x, y in zip(got, want)), (k, L)

@@ -125,7 +125,7 @@ impl PartialEq for FmIndex {
         if Arc::ptr_eq(&self.handle, &other.handle) {
             return true;
         }
-        let (a, b) = (self.raw(), other.raw());
+        let (a, b) = (self.raw() as *const sys::awry_index_t, other.raw() as *const sys::awry_index_t);
         unsafe {
             if sys::awry_alphabet(a) != sys::awry_alphabet(b)
                 || sys::awry_bwt_len(a) != sys::awry_bwt_len(b)
@@ -136,7 +136,7 @@ impl PartialEq for FmIndex {
             {
                 return false;
             }
-            let words = |f: unsafe extern "C" fn(*const sys::awry_index_t, *mut u64) -> *const u64, h| {
+            let words = |f: unsafe extern "C" fn(*const sys::awry_index_t, *mut u64) -> *const u64, h: *const sys::awry_index_t| {
                 let mut n = 0u64;
                 let p = f(h, &mut n);
                 std::slice::from_raw_parts(p, n as usize)
@@ -213,7 +213,7 @@ fn to_csr<'a>(queries: impl ParallelIterator<Item = &'a str>) -> Csr {
     let mut rest: &mut [u8] = &mut bytes;
     let mut parts: Vec<&mut [u8]> = Vec::with_capacity(list.len());
     for q in &list {
-        let (head, tail) = rest.split_at_mut(q.len());
+        let (head, tail) = std::mem::take(&mut rest).split_at_mut(q.len());
         parts.push(head);
         rest = tail;
     }

@@ -41,6 +41,33 @@ def make_text(n, alphabet=0, seed=0, n_records=1, n_frac=0.0, n_runs=3):
     return text, starts, ["seq%d" % i for i in range(len(starts))]
 
 
+def genome_like_text(n, seed=7):
+    """a text shaped like an assembled chromosome rather than i.i.d. letters: megabase runs of N (centromere / telomere
+    gaps), a 171-bp satellite array with 2 % divergence per copy, an exact tandem array of a 37-bp unit and four exact
+    segmental duplications -- the inputs on which prefix doubling needs many rounds and ranges stay wide.
+    Returns (text with a trailing '$', dict of the region starts / sizes)."""
+    rng = np.random.default_rng(seed)
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    text = acgt[rng.integers(0, 4, n, dtype=np.uint8)].copy()
+    gap, tel = n // 14, min(10_000, n // 300)
+    text[n // 2: n // 2 + gap] = ord("N")
+    text[:tel] = ord("N")
+    text[n - 1 - tel: n - 1] = ord("N")
+    sat0, copies = n // 2 + gap, min(20_000, (n // 8) // 171)
+    arr = np.tile(text[n // 250: n // 250 + 171], copies)
+    mut = rng.random(arr.size) < 0.02
+    arr[mut] = acgt[rng.integers(0, 4, int(mut.sum()), dtype=np.uint8)]
+    text[sat0: sat0 + arr.size] = arr
+    ex0, ecopies = sat0 + arr.size, min(50_000, (n // 16) // 37)
+    text[ex0: ex0 + 37 * ecopies] = np.tile(text[n // 125: n // 125 + 37], ecopies)
+    seg = min(200_000, n // 100)
+    for k in range(4):
+        src, dst = n // 80 + k * 3 * seg, n // 4 + k * 2 * seg
+        text[dst: dst + seg] = text[src: src + seg]
+    text[n - 1] = ord("$")
+    return text, dict(gap=gap, tel=tel, sat0=sat0, copies=copies, ex0=ex0, ecopies=ecopies, seg=seg, dup0=n // 4)
+
+
 def random_queries(nq, qlen, alphabet=0, seed=1):
     """uniform-random fixed-length queries -> uint8[nq, qlen]"""
     rng = np.random.default_rng(seed)

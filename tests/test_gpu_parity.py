@@ -242,6 +242,29 @@ def test_gpu_construction_degenerate_texts():
         assert np.array_equal(gpu.prefix_sums(), host.prefix_sums())
 
 
+def test_genome_like_text_construction_and_repeats(oracle):
+    """a chromosome-shaped text (megabase N gaps, satellite array, exact tandem array, segmental duplications,
+    synth.genome_like_text): the GPU construction needs ~15 doubling rounds and stays bit-identical to host SA-IS, and
+    queries from the repeats (wide ranges, thousands of hits) count and locate as in the oracle"""
+    n = 3_000_000
+    text, reg = synth.genome_like_text(n)
+    host = FmIndex.from_text(text, 0, 8, 0, [0], ["chrS"], build_device=-1)
+    gpu = FmIndex.from_text(text, 0, 8, 0, [0], ["chrS"], build_device=0)
+    assert np.array_equal(gpu.device_block_words(), host.device_block_words()) and np.array_equal(gpu.sa_words(), host.sa_words())
+    assert np.array_equal(gpu.prefix_sums(), host.prefix_sums()) and gpu.sentinel_row() == host.sentinel_row()
+    gpu.set_devices([0])
+    oi = oracle.OracleIndex.from_text(text, 0, 8, 0, [0], ["chrS"])
+    for starts, L in (([reg["dup0"] + 1000 * i for i in range(40)], 101), ([reg["sat0"] + 171 * 7 * i + 3 for i in range(40)], 60),
+                      ([reg["ex0"] + 5 * i for i in range(12)], 74), ([n // 2 + 5], 40)):
+        q2d = np.stack([text[s: s + L] for s in starts])
+        qb, qo = synth.fixed_to_csr(q2d)
+        ooff, ogpos, opos, _ = oi.parallel_locate(qb, qo, 4)
+        off, gpos, pos = gpu.parallel_locate_csr(qb, qo)
+        assert np.array_equal(off, ooff) and np.array_equal(gpos, ogpos) and np.array_equal(pos, opos), L
+        assert np.array_equal(gpu.parallel_count_csr(qb, qo), np.diff(ooff))
+    assert int(np.diff(ooff)[0]) == (reg["gap"] - 39) + 2 * (reg["tel"] - 39)   # the run of N's, by hand
+
+
 @pytest.mark.parametrize("L", [33, 50, 64, 65, 101, 150])
 def test_long_packed_reads_count_and_locate(oracle, L):
     """multi-word packed reads through the quad kernel + tile locate, against the oracle (same order)"""

@@ -265,6 +265,35 @@ def test_genome_like_text_construction_and_repeats(oracle):
     assert int(np.diff(ooff)[0]) == (reg["gap"] - 39) + 2 * (reg["tel"] - 39)   # the run of N's, by hand
 
 
+@pytest.mark.parametrize("L,nq", [(1000, 5000), (4096, 4200), (4097, 4200), (20000, 300)])
+def test_very_long_queries(oracle, L, nq):
+    """queries as long as contigs / long reads: 4096 letters is the longest packed query of the host path (128 words), 4097
+    and beyond go through the generic kernel; present (drawn from the text), one letter changed, and random queries"""
+    text, st, hd = synth.make_text(300000, 0, 53, 3, 0.0)
+    ix = gpu_index(text, 0, 8, 0, st, hd)
+    oi = oracle.OracleIndex.from_text(text, 0, 8, 0, st, hd)
+    rng = np.random.default_rng(L)
+    own = np.concatenate([np.array(st[1:]) - 1, [len(text) - 1]])          # delimiters and '$'
+    starts = rng.integers(0, len(text) - L - 1, size=nq)
+    starts = starts[np.searchsorted(own, starts) == np.searchsorted(own, starts + L)]   # windows inside one record
+    q2d = text[starts[:, None] + np.arange(L)[None, :]]
+    k = len(q2d) // 3
+    q2d[np.arange(k), rng.integers(0, L, size=k)] = ord("A")               # one letter set to A: absent three times in four
+    q2d[k: k + 5] = synth.random_queries(5, L, 0, 9)
+    qb, qo = synth.fixed_to_csr(q2d)
+    ooff, ogpos, opos, _ = oi.parallel_locate(qb, qo, 4)
+    assert (np.diff(ooff)[k + 5:] >= 1).all() and (np.diff(ooff) == 0).any()
+    assert np.array_equal(ix.parallel_count_csr(qb, qo), np.diff(ooff))
+    off, gpos, pos = ix.parallel_locate_csr(qb, qo)
+    assert np.array_equal(off, ooff) and np.array_equal(gpos, ogpos) and np.array_equal(pos, opos)
+    # unequal lengths around the same size
+    lens = rng.integers(max(1, L - 70), L + 1, size=len(q2d))
+    qb2 = np.concatenate([q2d[i, L - lens[i]:] for i in range(len(q2d))])
+    qo2 = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    oc2, _ = oi.parallel_count(qb2, qo2, 4)
+    assert np.array_equal(ix.parallel_count_csr(qb2, qo2), oc2)
+
+
 @pytest.mark.parametrize("L", [33, 50, 64, 65, 101, 150])
 def test_long_packed_reads_count_and_locate(oracle, L):
     """multi-word packed reads through the quad kernel + tile locate, against the oracle (same order)"""

@@ -1089,7 +1089,7 @@ def test_host_packed_boundary_details(oracle):
     32-bit words over PCIe): a batch of several chunks in which a third of the queries hold other letters (N, IUPAC codes,
     U, lower case) and travel as compact batches for the generic kernel; the first undefined query is named by its index;
     hits_out = NULL returns the same offsets and text positions without (record, offset) pairs"""
-    text, st, hd = synth.make_text(500000, 0, 91, 4, 0.03)
+    text, st, hd = synth.make_text(500000, 0, 91, 4, 0.004)  # (short runs of N: a query of N's inside one matches all of it)
     ix = gpu_index(text, 0, 8, 0, st, hd)
     oi = oracle.OracleIndex.from_text(text, 0, 8, 0, st, hd)
     rng = np.random.default_rng(5)

@@ -607,13 +607,16 @@ void launch_locate(Replica& r, const uint64_t* d_range_start, int rs_stride, con
   unsigned long long* ctr = next_counter(r, s);
   const uint64_t tiles = (total + LOC_TILE - 1) / LOC_TILE;
   const dim3 g((unsigned)std::min<uint64_t>(tiles, (uint64_t)r.num_cus * 8)), b(256);
+  // consecutive tiles a block draws at a time (one search of the whole offset array per run): long enough to amortise
+  // that search, short enough that every block still draws several runs and the launch ends evenly
+  const uint32_t run_len = (uint32_t)std::min<uint64_t>(16, std::max<uint64_t>(1, tiles / ((uint64_t)g.x * 4)));
   const uint32_t* dense = r.dense_ratio ? r.dense_sa.p : nullptr;
   if (r.dev.alphabet == NUCLEOTIDE)
     hipLaunchKernelGGL(locate_tile_kernel<NUCLEOTIDE>, g, b, 0, s, r.dev, d_range_start, rs_stride, d_hit_off, n, total, dense, r.dense_ratio,
-                       d_gpos, d_pos, ctr);
+                       d_gpos, d_pos, ctr, run_len);
   else
     hipLaunchKernelGGL(locate_tile_kernel<AMINO>, g, b, 0, s, r.dev, d_range_start, rs_stride, d_hit_off, n, total, dense, r.dense_ratio,
-                       d_gpos, d_pos, ctr);
+                       d_gpos, d_pos, ctr, run_len);
   HIP_CHECK(hipGetLastError());
   if (r.dense_ratio == 1) return;  // every row is a sampled row: nothing was deferred
   // the hits whose row is not sampled walk in a second pass that is not tied to tiles (locate_walk_kernel)

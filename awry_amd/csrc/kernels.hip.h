@@ -1920,6 +1920,8 @@ __global__ __launch_bounds__(256) void count_nt2_reads_probe_kernel(DevIndex ix,
   __shared__ unsigned int s_count;
   __shared__ uint32_t s_vsp[4][VQ], s_vq[4][VQ];
   __shared__ uint8_t s_vn[4][VQ];
+  __shared__ uint16_t s_vl[RAGGED ? 4 : 1][VQ];  // RAGGED: the read's length (<= 512 on this path)
+  __shared__ uint64_t s_vw[4][3][VQ];  // the letters left of the seed window of a queued read (<= 96 of them: three words)
   if (threadIdx.x == 0) s_count = 0;
   __syncthreads();
   const int lane = threadIdx.x & 63, wv_id = threadIdx.x >> 6;
@@ -1932,6 +1934,9 @@ __global__ __launch_bounds__(256) void count_nt2_reads_probe_kernel(DevIndex ix,
   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
   const uint64_t lane_lt = (1ull << lane) - 1;
   const uint64_t region = (uint64_t)blockIdx.x * sv.cap;
+  // a queued read is compared with the text a few hundred seed probes after its words were read: by then the random seed
+  // lines have pushed them out of L2, so the words wait in LDS beside the queue entry instead of being fetched again
+  const bool stash = L - k <= 96;
   int vcount = 0;
   auto settle = [&](uint64_t q, uint64_t count, uint64_t rs) {
     counts[q] = count;
@@ -1952,7 +1957,7 @@ __global__ __launch_bounds__(256) void count_nt2_reads_probe_kernel(DevIndex ix,
 #pragma unroll
     for (int h = 0; h < 2; h++) {
       if (!on[h]) continue;
-      const int i0 = (RAGGED ? (int)lens[q[h]] : L) - k, nchunks = (i0 + 31) >> 5;
+      const int i0 = (RAGGED ? (int)s_vl[RAGGED ? wv_id : 0][base + lane + 64 * h] : L) - k, nchunks = (i0 + 31) >> 5;
       const uint64_t* qw = queries + (uint64_t)q[h] * W;
       uint32_t mask = 0;
       uint64_t g1 = 0;
@@ -1960,16 +1965,18 @@ __global__ __launch_bounds__(256) void count_nt2_reads_probe_kernel(DevIndex ix,
         const uint32_t p = c2 ? ix.dense_sa[sp[h] + c2] : vp[h];
         uint32_t bad = p >= (uint32_t)i0 ? 0u : 1u;  // else the suffix starts too close to the text's beginning
         const uint64_t g = (uint64_t)p - (uint64_t)i0;
-        for (int c = 0; c < nchunks && !bad; c++) bad = verify_part(ix.text4, g, i0, c >> 2, c & 3, qw[c]);
+        for (int c = 0; c < nchunks && !bad; c++)
+          bad = verify_part(ix.text4, g, i0, c >> 2, c & 3, stash ? s_vw[wv_id][c][base + lane + 64 * h] : qw[c]);
         if (!bad) { mask |= 1u << c2; g1 = g; }
       }
       if (nc[h] == 1u && mask) settle(q[h], 1, (RS_SINGLE << RS_MODE_SHIFT) | g1);
       else settle(q[h], (uint64_t)__popc(mask), (RS_MULTI << RS_MODE_SHIFT) | (uint64_t)sp[h] | ((uint64_t)i0 << 32) | ((uint64_t)mask << 48));
     }
   };
-  constexpr int NQ = 2;  // reads in flight per lane
+  constexpr int NQ = 2;  // reads in flight per lane (3 and 4 measure the same)
   for (uint64_t wbase = (uint64_t)blockIdx.x * blockDim.x + (threadIdx.x & ~63u); wbase < n; wbase += NQ * stride) {
     uint64_t qv[NQ], win[NQ];
+    uint64_t lw[NQ][3];
     uint32_t nc[NQ];
     bool probe[NQ];  // false: too short for the per-lane path (fewer than 3 letters left of the seed window)
     SeedEntry ev[NQ];
@@ -1989,6 +1996,10 @@ __global__ __launch_bounds__(256) void count_nt2_reads_probe_kernel(DevIndex ix,
           win[h] = qw[wa] >> wsh;
           if (wsh && wa + 1 < W) win[h] |= qw[wa + 1] << (64 - wsh);
           nc[h] = (uint32_t)(qw[na] >> nsh) & 3u;
+          if (stash) {
+#pragma unroll
+            for (int c = 0; c < 3; c++) lw[h][c] = c < W ? qw[c] : 0;
+          }
         }
       }
     }
@@ -2037,6 +2048,11 @@ __global__ __launch_bounds__(256) void count_nt2_reads_probe_kernel(DevIndex ix,
           s_vsp[wv_id][s] = cnt == 1u && pos ? seed_position(e, cx) : e.sp;
           s_vq[wv_id][s] = (uint32_t)qv[h];
           s_vn[wv_id][s] = (uint8_t)cnt;
+          if (RAGGED) s_vl[wv_id][s] = (uint16_t)lens[qv[h]];
+          if (stash) {
+#pragma unroll
+            for (int c = 0; c < 3; c++) s_vw[wv_id][c][s] = lw[h][c];
+          }
         }
         vcount += (int)__popcll(qm);
         __builtin_amdgcn_wave_barrier();
@@ -2159,66 +2175,88 @@ __global__ __launch_bounds__(256) void text8_scatter_kernel(DevIndex ix, uint8_t
   }
 }
 
-// hits [tile * LOC_TILE, ...) handed out by an atomic tile head; inside a tile every lane is a small state
-// machine (take a hit -> walk one backstep per iteration -> emit), so lanes whose walk ends early take the next
-// hit instead of idling behind the longest walk of the wave.
+// largest query q >= lo with hit_off[q] <= h (the query that owns hit h; queries without hits are skipped because their
+// offset equals their successor's).  Needs hit_off[lo] <= h; hit_off has n + 1 entries and hit_off[n] = total > h.
+// Gallops from lo: the owner of a tile's first hit is usually a few queries past the previous tile's.
+__device__ __forceinline__ uint64_t owner_from(const uint64_t* __restrict__ hit_off, uint64_t lo, uint64_t n, uint64_t h) {
+  uint64_t a = lo, step = 1;
+  while (a + step < n && hit_off[a + step] <= h) { a += step; step <<= 1; }
+  uint64_t hi = a + step < n ? a + step : n;
+  while (hi - a > 1) { const uint64_t mid = (a + hi) >> 1; if (hit_off[mid] <= h) a = mid; else hi = mid; }
+  return a;
+}
+
+// Hits in tiles of LOC_TILE; a block draws RUNS of consecutive tiles from an atomic head (run_len tiles at a time: the
+// launcher picks it so that every block still gets several runs).  Only the first tile of a run searches the whole offset
+// array for the query that owns its first hit (27 dependent loads at GRCh38 batch sizes -- per tile that chain was most
+// of this kernel's time); the next tile's owner is read off the offsets the block already holds in LDS.  Per tile the
+// offsets and range words of up to LOC_QCAP queries are staged in LDS and every hit finds its query there.  A hit whose
+// row is a sampled one (or whose count pass left a text position) is emitted here; the others are flagged for the walk
+// kernels, so every hit costs the same and the hits of a tile are dealt out statically.
 template <int A>
 __global__ __launch_bounds__(256) void locate_tile_kernel(DevIndex ix, const uint64_t* __restrict__ range_start, int rs_stride,
                                                           const uint64_t* __restrict__ hit_off, uint64_t n, uint64_t total,
                                                           const uint32_t* __restrict__ dense, uint32_t dense_ratio,
                                                           uint64_t* __restrict__ gpos, uint64_t* __restrict__ pos,
-                                                          unsigned long long* __restrict__ tile_counter) {
+                                                          unsigned long long* __restrict__ tile_counter, uint32_t run_len) {
   __shared__ uint64_t s_off[LOC_QCAP + 1];
   __shared__ uint64_t s_sp[LOC_QCAP];
   __shared__ uint64_t s_starts[LOC_SEQ_LDS];
   __shared__ unsigned long long s_tile;
-  __shared__ uint64_t s_q[2];
-  __shared__ int s_cursor;
+  __shared__ uint64_t s_q0;
   const bool seq_lds = pos && ix.nseq <= (uint64_t)LOC_SEQ_LDS;
   if (seq_lds)
     for (uint64_t t = threadIdx.x; t < ix.nseq; t += blockDim.x) s_starts[t] = ix.seq_starts[t];
   const uint64_t ntiles = (total + LOC_TILE - 1) / LOC_TILE;
   for (;;) {
-    if (threadIdx.x == 0) { s_tile = atomicAdd(tile_counter, 1ull); s_cursor = 0; }
-    __syncthreads();
-    const uint64_t tile = s_tile;
-    if (tile >= ntiles) break;
-    const uint64_t h0 = tile * LOC_TILE;
-    const int tn = (int)(total - h0 < (uint64_t)LOC_TILE ? total - h0 : (uint64_t)LOC_TILE);
-    if (threadIdx.x < 2) {  // queries holding the first and the last hit of the tile
-      const uint64_t h = threadIdx.x == 0 ? h0 : h0 + tn - 1;
-      uint64_t lo = 0, hi = n;
-      while (hi - lo > 1) { uint64_t mid = (lo + hi) >> 1; if (hit_off[mid] <= h) lo = mid; else hi = mid; }
-      s_q[threadIdx.x] = lo;
+    if (threadIdx.x == 0) {
+      const unsigned long long t0 = atomicAdd(tile_counter, (unsigned long long)run_len);
+      s_tile = t0;
+      if (t0 < ntiles) {  // owner of the run's first hit: plain binary search over all queries
+        const uint64_t h = t0 * LOC_TILE;
+        uint64_t lo = 0, hi = n;
+        while (hi - lo > 1) { const uint64_t mid = (lo + hi) >> 1; if (hit_off[mid] <= h) lo = mid; else hi = mid; }
+        s_q0 = lo;
+      }
     }
     __syncthreads();
-    const uint64_t q0 = s_q[0], nq = s_q[1] - s_q[0] + 1;
-    const bool cached = nq <= (uint64_t)LOC_QCAP;
-    if (cached) {
-      for (uint64_t t = threadIdx.x; t <= nq; t += blockDim.x) s_off[t] = hit_off[q0 + t];
-      for (uint64_t t = threadIdx.x; t < nq; t += blockDim.x) s_sp[t] = range_start[(q0 + t) * rs_stride];
-    }
-    __syncthreads();
-    bool need = true, direct = false;
-    uint64_t h = 0, row = 0, gd = 0;
-    for (;;) {
-      if (need) {
-        const int t = atomicAdd(&s_cursor, 1);
-        if (t >= tn) break;
-        h = h0 + t;
-        uint64_t lo = 0, hi = cached ? nq : n;  // largest query with offset <= h (skips queries without hits)
-        uint64_t rs, j;  // the query's range-start word and the index of this hit inside the query
+    const uint64_t run0 = s_tile;
+    if (run0 >= ntiles) break;
+    const uint64_t run1 = run0 + run_len < ntiles ? run0 + run_len : ntiles;
+    for (uint64_t tile = run0; tile < run1; tile++) {
+      const uint64_t h0 = tile * LOC_TILE;
+      const int tn = (int)(total - h0 < (uint64_t)LOC_TILE ? total - h0 : (uint64_t)LOC_TILE);
+      const uint64_t h_last = h0 + (uint64_t)tn - 1;
+      const uint64_t q0 = s_q0;
+      const uint64_t nload = n - q0 < (uint64_t)LOC_QCAP ? n - q0 : (uint64_t)LOC_QCAP;  // queries q0 .. q0 + nload - 1
+      for (uint64_t t = threadIdx.x; t <= nload; t += blockDim.x) s_off[t] = hit_off[q0 + t];
+      __syncthreads();
+      // do the staged queries own the whole tile?  (not when it spans more than LOC_QCAP queries, most of them without hits)
+      const bool cached = s_off[nload] > h_last;
+      uint64_t nq = nload;  // staged queries that own a hit of the tile: the range words of the others are not needed
+      if (cached) {
+        uint64_t lo = 0, hi = nload;
+        while (hi - lo > 1) { const uint64_t mid = (lo + hi) >> 1; if (s_off[mid] <= h_last) lo = mid; else hi = mid; }
+        nq = lo + 1;
+        for (uint64_t t = threadIdx.x; t < nq; t += blockDim.x) s_sp[t] = range_start[(q0 + t) * rs_stride];
+      }
+      __syncthreads();
+      for (int t = threadIdx.x; t < tn; t += blockDim.x) {
+        const uint64_t h = h0 + (uint64_t)t;
+        uint64_t rs, j;  // the owning query's range-start word and the index of this hit inside the query
         if (cached) {
-          while (hi - lo > 1) { uint64_t mid = (lo + hi) >> 1; if (s_off[mid] <= h) lo = mid; else hi = mid; }
+          uint64_t lo = 0, hi = nq;
+          while (hi - lo > 1) { const uint64_t mid = (lo + hi) >> 1; if (s_off[mid] <= h) lo = mid; else hi = mid; }
           rs = s_sp[lo];
           j = h - s_off[lo];
         } else {
-          while (hi - lo > 1) { uint64_t mid = (lo + hi) >> 1; if (hit_off[mid] <= h) lo = mid; else hi = mid; }
+          const uint64_t lo = owner_from(hit_off, q0, n, h);
           rs = range_start[lo * rs_stride];
           j = h - hit_off[lo];
         }
         const uint64_t rmode = rs >> RS_MODE_SHIFT;
-        direct = rmode != RS_PLAIN;
+        bool direct = rmode != RS_PLAIN;
+        uint64_t row = 0, gd = 0;
         if (rmode == RS_SINGLE) {
           gd = rs & ((1ull << 40) - 1);  // the count pass already verified this match against the text
         } else if (rmode == RS_MULTI) {
@@ -2229,22 +2267,30 @@ __global__ __launch_bounds__(256) void locate_tile_kernel(DevIndex ix, const uin
         } else {
           row = rs + j;
         }
-        need = false;
-      }
-      if (direct || row_is_sampled(ix, dense, dense_ratio, row)) {
-        const uint64_t g = direct ? gd : walked_position(row_sample(ix, dense, dense_ratio, row), 0, ix.bwt_len);  // src/fm_index.rs:534, 0 steps
-        gpos[h] = g;
-        if (pos) {
-          if (seq_lds) localise_lds(s_starts, ix.nseq, g, pos + 2 * h);
-          else localise(ix, g, pos + 2 * h);
+        if (direct || row_is_sampled(ix, dense, dense_ratio, row)) {
+          const uint64_t g = direct ? gd : walked_position(row_sample(ix, dense, dense_ratio, row), 0, ix.bwt_len);  // src/fm_index.rs:534, 0 steps
+          gpos[h] = g;
+          if (pos) {
+            if (seq_lds) localise_lds(s_starts, ix.nseq, g, pos + 2 * h);
+            else localise(ix, g, pos + 2 * h);
+          }
+        } else {
+          gpos[h] = row | LOC_WALK_FLAG;  // a walk kernel finishes this hit,
+          if (pos) pos[2 * h] = ~0ull;    // localise_walked_kernel its record / offset
         }
-      } else {
-        gpos[h] = row | LOC_WALK_FLAG;  // a walk kernel finishes this hit,
-        if (pos) pos[2 * h] = ~0ull;    // localise_walked_kernel its record / offset
       }
-      need = true;
+      if (threadIdx.x == 0 && tile + 1 < run1) {  // owner of the next tile's first hit
+        const uint64_t hn = h0 + (uint64_t)LOC_TILE;
+        if (cached) {
+          uint64_t lo = nq - 1, hi = nload + 1;   // s_off[nq - 1] <= h_last < hn
+          while (hi - lo > 1) { const uint64_t mid = (lo + hi) >> 1; if (s_off[mid] <= hn) lo = mid; else hi = mid; }
+          s_q0 = lo < nload ? q0 + lo : owner_from(hit_off, q0 + nload, n, hn);  // (lo == nload: the staged offsets end at or before hn)
+        } else {
+          s_q0 = owner_from(hit_off, q0, n, hn);
+        }
+      }
+      __syncthreads();
     }
-    __syncthreads();
   }
 }
 

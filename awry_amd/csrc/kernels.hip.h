@@ -463,7 +463,7 @@ __device__ __forceinline__ uint32_t jn_idx(uint64_t i0, uint64_t i1, uint64_t i2
   return (uint32_t)((w >> (8 * (j & 7))) & 0xFF);
 }
 constexpr int AA_KMER_VMULTI = 4;        // seed ranges of up to this many rows are verified candidate by candidate
-constexpr int AA_KMER_VMULTI_LANES = 8;  //   when at least this many lanes of the wave hold one
+constexpr int AA_KMER_VMULTI_LANES = 8;  //   when at least this many lanes of the wave hold one (1 and 3 measure no better)
 
 // RAGGED: query q is ascii[off[q], off[q + 1]) with its own length (k .. AA_KMER_MAX residues take this pass, any other
 // length is listed for the generic kernel); L is then ignored.  Same per-lane work with the length, the number of

@@ -450,6 +450,14 @@ std::unique_ptr<Replica> make_replica(awry_index* ix, int device) {
   HIP_CHECK(hipEventCreate(&r->ev0));
   HIP_CHECK(hipEventCreate(&r->ev1));
   const HostIndex& h = ix->host;
+  static const bool verbose = getenv("AWRY_VERBOSE") != nullptr;
+  auto t_last = std::chrono::steady_clock::now();
+  auto lap = [&](const char* what) {  // AWRY_VERBOSE: where the seconds of a replica's construction go
+    if (!verbose) return;
+    const auto t = std::chrono::steady_clock::now();
+    fprintf(stderr, "[awry replica %d] %s: %.2f s\n", device, what, std::chrono::duration<double>(t - t_last).count());
+    t_last = t;
+  };
   r->blocks.alloc(h.blocks.size());
   r->sa_words.alloc(h.sa_words.size() + 1);  // +1: the straddle read of the last sample never leaves the buffer
   r->seq_starts.alloc(std::max<size_t>(1, h.seq_starts.size()));
@@ -482,8 +490,11 @@ std::unique_ptr<Replica> make_replica(awry_index* ix, int device) {
   d.sa_nblock = nullptr;
   d.seed_pos = 0;
   d.ctx_extra = 0;
+  lap("index upload");
   build_seed(ix, *r, ix->seed_k_request < 0 ? default_seed_k(h) : ix->seed_k_request);
+  lap("seed table");
   build_dense_sa(ix, *r, ix->dense_ratio_request);
+  lap("dense SA");
   int vreq = ix->verify_request;
   if (vreq == -2) {  // policy: keep the accelerators (dense SA 4 B + text 1.5 B / 1 B per symbol) resident when they fit comfortably
     vreq = -1;
@@ -493,9 +504,11 @@ std::unique_ptr<Replica> make_replica(awry_index* ix, int device) {
       vreq = e && atoi(e) > 0 ? atoi(e) : 2;
   }
   if (vreq >= 0) build_verify(ix, *r, vreq);
+  lap("verify accelerators (dense SA at ratio 1, text)");
   r->verify_kmers = ix->verify_kmers_request;
   refresh_nblock(ix, *r);
   sync_seed_mode(ix, *r);
+  lap("block-of-sample table, seed mode");
   return r;
 }
 

@@ -242,6 +242,30 @@ def test_gpu_construction_degenerate_texts():
         assert np.array_equal(gpu.prefix_sums(), host.prefix_sums())
 
 
+def test_locate_tiles_with_sparse_and_heavy_queries(oracle):
+    """the locate tile kernel stages the offsets of up to 1024 queries per tile of 1024 hits and derives the next tile's first
+    query from them: batches where most queries have no hit (a tile spans tens of thousands of queries), where single queries
+    own tens of tiles, and mixtures, against the oracle -- through the host path (chunks) and the device-resident stages"""
+    text, st, hd = synth.make_text(300000, 0, 61, 3, 0.02)
+    ix = gpu_index(text, 0, 8, 0, st, hd)
+    oi = oracle.OracleIndex.from_text(text, 0, 8, 0, st, hd)
+    rng = np.random.default_rng(8)
+    sparse = [bytes(x) for x in synth.random_queries(120000, 12, 0, 3)]          # ~2 % present
+    heavy = [b"A", b"CG", b"T", b"GAT"]                                            # 5 000 .. 75 000 hits each
+    mixed = list(sparse[:50000])
+    for j, pos in enumerate(rng.integers(0, len(mixed), size=12)):
+        mixed.insert(int(pos), heavy[j % len(heavy)])
+    dense = [bytes(x) for x in synth.sampled_queries(text, 30000, 20, 4)]          # one hit or a few per query
+    for qs in (sparse, mixed, heavy * 3, dense + sparse[:30000] + dense):
+        qb, qo = awry_pack(qs)
+        ooff, ogpos, opos, _ = oi.parallel_locate(qb, qo, 4)
+        for dens in (0, 1):
+            ix.set_locate_sa_ratio(dens)
+            off, gpos, pos = ix.parallel_locate_csr(qb, qo)
+            assert np.array_equal(off, ooff) and np.array_equal(gpos, ogpos) and np.array_equal(pos, opos), (len(qs), dens)
+    ix.set_locate_sa_ratio(0)
+
+
 def test_genome_like_text_construction_and_repeats(oracle):
     """a chromosome-shaped text (megabase N gaps, satellite array, exact tandem array, segmental duplications,
     synth.genome_like_text): the GPU construction needs ~15 doubling rounds and stays bit-identical to host SA-IS, and

@@ -1984,6 +1984,7 @@ static void construct(awry_index* ix, const uint8_t* text, uint64_t bwt_len, int
   if (bwt_len == 0 || text[bwt_len - 1] != '$') throw ArgError("text must end with '$'");
   std::vector<uint8_t> canon;
   if (canonical_text(text, bwt_len, alphabet, canon)) text = canon.data();
+  const bool automatic = build_device == AWRY_BUILD_AUTO;
   if (build_device == AWRY_BUILD_AUTO) {
     const char* e = getenv("AWRY_BUILD");
     int ndev = 0;
@@ -2003,7 +2004,14 @@ static void construct(awry_index* ix, const uint8_t* text, uint64_t bwt_len, int
   } catch (const std::bad_alloc&) {
     throw;
   } catch (const std::exception& e) {
-    throw HipError(std::string("GPU index construction: ") + e.what());
+    // Construction is host work in the reference; the GPU is how it gets fast here, not a requirement.  When the device
+    // was chosen automatically and cannot do it (its HBM is taken by replicas, say: the builder needs ~45 B per symbol),
+    // the host builder produces the same index, only slower.  An explicit device request fails loudly instead.
+    if (!automatic) throw HipError(std::string("GPU index construction: ") + e.what());
+    (void)hipGetLastError();
+    if (getenv("AWRY_VERBOSE")) fprintf(stderr, "[awry] GPU index construction failed (%s): building on the host\n", e.what());
+    ix->host = HostIndex();
+    build_from_text(ix->host, text, bwt_len, alphabet, sa_ratio, kmer_len, seq_starts, headers, nseq);
   }
 }
 

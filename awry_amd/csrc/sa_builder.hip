@@ -13,6 +13,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -325,6 +326,7 @@ unsigned bits_for(uint64_t v) { unsigned b = 0; while (b < 64 && (v >> b)) b++; 
 // ix.blocks / sa_words / prefix_sums / sentinel_row exactly as pack_index() does.  n must be < 2^32 - 1.
 void gpu_build_index(HostIndex& ix, const uint8_t* text, uint64_t n, int device, bool verbose) {
   if (n >= (1ull << 32) - 1) throw GpuBuildError("GPU index construction needs bwt_len < 2^32");
+  if (getenv("AWRY_DEBUG_FAIL_GPU_BUILD")) throw GpuBuildError("forced failure (AWRY_DEBUG_FAIL_GPU_BUILD)");  // tests: the host fallback
   const int A = ix.alphabet;
   if (A == AMINO && n >= (1ull << 32)) throw GpuBuildError("amino bwt_len >= 2^32 unsupported");
   GB_CHECK(hipSetDevice(device));

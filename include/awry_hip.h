@@ -61,7 +61,8 @@ int awry_build_from_text(const uint8_t *text, uint64_t bwt_len, int alphabet, ui
 /* same with an explicit choice of where the suffix array and the BWT are constructed: a device id >= 0
  * (GPU prefix doubling + streaming pack kernels), AWRY_BUILD_HOST (host SA-IS) or AWRY_BUILD_AUTO (what
  * awry_build / awry_build_from_text use: the calling thread's current GPU if one is visible and bwt_len >= 2^20, else host; env AWRY_BUILD=host|gpu
- * overrides).  All choices produce bit-identical indexes. */
+ * overrides; when the GPU chosen this way cannot do it -- its HBM taken by replicas, say -- the host builder takes over, while
+ * an explicit device id fails with AWRY_ERR_HIP).  All choices produce bit-identical indexes. */
 enum { AWRY_BUILD_HOST = -1, AWRY_BUILD_AUTO = -2 };
 int awry_build_from_text_on(const uint8_t *text, uint64_t bwt_len, int alphabet, uint64_t sa_ratio, uint8_t kmer_len,
                             const uint64_t *seq_starts, const char *const *headers, uint64_t nseq, int build_device,

@@ -266,6 +266,25 @@ def test_locate_tiles_with_sparse_and_heavy_queries(oracle):
     ix.set_locate_sa_ratio(0)
 
 
+def test_automatic_gpu_construction_falls_back_to_the_host(monkeypatch):
+    """AWRY_BUILD_AUTO picks the GPU for texts of 2^20 symbols and more; when that GPU cannot build (forced here; in the field:
+    its HBM is taken) the host builder produces the same index, while an explicit device request fails loudly"""
+    from awry_amd.fm_index import BUILD_AUTO
+    text, st, hd = synth.make_text((1 << 20) + 5000, 0, 71, 2, 0.01)
+    gpu = FmIndex.from_text(text, 0, 8, 0, st, hd, build_device=0)
+    monkeypatch.setenv("AWRY_DEBUG_FAIL_GPU_BUILD", "1")
+    with pytest.raises(AwryError) as e:
+        FmIndex.from_text(text, 0, 8, 0, st, hd, build_device=0)
+    assert "GPU index construction" in str(e.value)
+    auto = FmIndex.from_text(text, 0, 8, 0, st, hd, build_device=BUILD_AUTO)
+    monkeypatch.delenv("AWRY_DEBUG_FAIL_GPU_BUILD")
+    assert np.array_equal(auto.device_block_words(), gpu.device_block_words()) and np.array_equal(auto.sa_words(), gpu.sa_words())
+    assert np.array_equal(auto.prefix_sums(), gpu.prefix_sums()) and auto.sentinel_row() == gpu.sentinel_row()
+    auto.set_devices([0])
+    q = synth.sampled_queries(text, 2000, 25, 3)
+    assert (auto.parallel_count_csr(*synth.fixed_to_csr(q)) >= 1).all()
+
+
 def test_genome_like_text_construction_and_repeats(oracle):
     """a chromosome-shaped text (megabase N gaps, satellite array, exact tandem array, segmental duplications,
     synth.genome_like_text): the GPU construction needs ~15 doubling rounds and stays bit-identical to host SA-IS, and

@@ -551,7 +551,12 @@ void launch_aa_two_phase(Replica& r, const uint8_t* d_q, const uint64_t* d_off, 
   // chain over a few per cent of the batch; running it for the first half of a batch on a side stream beside the first
   // pass of the second half (event fork / join) was measured and costs more than it hides (12.7 -> 10.7 G present
   // 12-mers/s, host path 0.83 -> 0.52 G queries/s).
-  if (d_off) hipLaunchKernelGGL((count_aa_kmer_probe_kernel<2, true>), dim3(nblk), dim3(256), 0, s, r.dev, d_q, d_off, n, 0, d_counts, d_ranges, d_status, ql);
+  // queries of more than 24 residues (up to AA_KMER_LONG_MAX): the LONG instantiations -- the same pass over a query's last 24
+  // residues plus a comparison of the rest with the text for the candidates that are left
+  static const bool no_long = getenv("AWRY_AA_LONG") && !strcmp(getenv("AWRY_AA_LONG"), "0");
+  if (d_off && !no_long) hipLaunchKernelGGL((count_aa_kmer_probe_kernel<2, true, true>), dim3(nblk), dim3(256), 0, s, r.dev, d_q, d_off, n, 0, d_counts, d_ranges, d_status, ql);
+  else if (d_off) hipLaunchKernelGGL((count_aa_kmer_probe_kernel<2, true>), dim3(nblk), dim3(256), 0, s, r.dev, d_q, d_off, n, 0, d_counts, d_ranges, d_status, ql);
+  else if (L > AA_KMER_MAX) hipLaunchKernelGGL((count_aa_kmer_probe_kernel<2, false, true>), dim3(nblk), dim3(256), 0, s, r.dev, d_q, d_off, n, L, d_counts, d_ranges, d_status, ql);
   else hipLaunchKernelGGL((count_aa_kmer_probe_kernel<2, false>), dim3(nblk), dim3(256), 0, s, r.dev, d_q, d_off, n, L, d_counts, d_ranges, d_status, ql);
   hipLaunchKernelGGL((count_scalar_kernel<AMINO, LIST_BLOCK>), dim3(nblk2), dim3(256), 0, s, r.dev, d_q, d_off, n, d_counts, d_ranges, d_status, 1,
                      d_off ? 0 : (uint64_t)L, ql);
@@ -951,8 +956,9 @@ void launch_count_ascii_uniform(Replica& r, const uint8_t* d_q, uint64_t n, uint
   if (n == 0) return;
   require(L >= 1, "query length must be at least 1");
   static const bool off = getenv("AWRY_AA_KMER") && !strcmp(getenv("AWRY_AA_KMER"), "0");
-  const bool two_phase = !off && r.dev.alphabet == AMINO && L >= (uint64_t)AA_KMER_MIN && L <= (uint64_t)AA_KMER_MAX && r.seed_k >= 1 &&
-                         (uint64_t)r.seed_k <= L && n < (1ull << 32);
+  static const bool no_long = getenv("AWRY_AA_LONG") && !strcmp(getenv("AWRY_AA_LONG"), "0");
+  const bool two_phase = !off && r.dev.alphabet == AMINO && L >= (uint64_t)AA_KMER_MIN && L <= (uint64_t)(no_long ? AA_KMER_MAX : AA_KMER_LONG_MAX) &&
+                         r.seed_k >= 1 && (uint64_t)r.seed_k <= L && n < (1ull << 32);
   Replica::SurvScratch* sc = surv_scratch(r, s);
   if (r.dev.alphabet == NUCLEOTIDE && !d_ranges && L <= 4096 && n < (1ull << 32)) {
     // the device half of the packed host path: pack 2 bits per letter, packed kernels, and the generic kernel over the

@@ -1337,7 +1337,62 @@ def test_swissprot_scale_amino_12mers(oracle, tmp_path):
     assert np.array_equal(ix.parallel_count_csr(rb, ro), want)
 
 
-@pytest.mark.parametrize("lo,hi", [(1, 40), (8, 24), (5, 13)])
+@pytest.mark.parametrize("L", [25, 31, 40, 64, 333, 1024, 1025])
+def test_amino_long_queries_of_one_length(oracle, L):
+    """amino queries of more than 24 residues (peptides, protein fragments; up to 1024 take the k-mer schedule's LONG pass:
+    the last 24 residues as for k-mers, the rest screened for undefined bytes and compared with the text for surviving
+    candidates; 1025 goes to the generic kernel): from the text (some from a duplicated region: several candidates), with
+    one residue changed in the far or in the near part, random, X / unknown letters, lower case, windows at the very
+    beginning of the text -- device-resident, parallel_count and parallel_locate against the oracle"""
+    import torch
+    text, st, hd = synth.make_text(300000, 1, 95, 12, 0.0)
+    text = text.copy()
+    text[150000:153000] = text[3000:6000]
+    ix = gpu_index(text, 1, 8, 0, st, hd)
+    oi = oracle.OracleIndex.from_text(text, 1, 8, 0, st, hd)
+    rng = np.random.default_rng(L)
+    nq = 9000
+    starts = rng.integers(0, len(text) - L - 2, size=nq)
+    starts[:1500] = rng.integers(3000, 6000 - min(L, 2900), size=1500)
+    starts[1500:1520] = np.arange(20)
+    q2d = text[starts[:, None] + np.arange(L)[None, :]].copy()
+    q2d[q2d == ord("$")] = ord("A")
+    far_mut = np.arange(3000, 4500)
+    q2d[far_mut, rng.integers(0, L - 24, size=len(far_mut))] = synth.AA[rng.integers(0, 20, size=len(far_mut))]
+    near_mut = np.arange(4500, 5500)
+    q2d[near_mut, rng.integers(L - 24, L, size=len(near_mut))] = synth.AA[rng.integers(0, 20, size=len(near_mut))]
+    q2d[5500:6000] = synth.random_queries(500, L, 1, L)
+    odd = rng.random(q2d.shape) < 0.0005
+    odd[1500:1520] = False
+    q2d[odd] = np.frombuffer(b"XBZJ7*", dtype=np.uint8)[rng.integers(0, 6, size=int(odd.sum()))]
+    q2d[6000:6500] |= 0x20
+    qb, qo = synth.fixed_to_csr(q2d)
+    want_loc = oi.parallel_locate(qb, qo, 4)[:3]
+    want = np.diff(want_loc[0])
+    assert (want > 1).sum() > 100 and (want == 0).sum() > 500 and (want[1500:1520] >= 1).all()
+    dev = torch.device("cuda", 0)
+    d_q = torch.from_numpy(np.concatenate([qb, np.zeros(16, dtype=np.uint8)])).to(dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    for verify in (2, -1):
+        ix.set_verify(verify)
+        for k in (-1, 3):
+            ix.set_seed_kmer_len(k)
+            d_c = torch.full((nq,), -1, dtype=torch.int64, device=dev)
+            ix.dev_count_ascii_uniform(d_q.data_ptr(), nq, L, d_c.data_ptr(), None, stream, 0)
+            torch.cuda.synchronize()
+            assert np.array_equal(d_c.cpu().numpy().astype(np.uint64), want), (verify, k)
+            assert np.array_equal(ix.parallel_count_csr(qb, qo), want), (verify, k)
+            got = ix.parallel_locate_csr(qb, qo)
+            assert all(np.array_equal(x, y) for x, y in zip(got, want_loc)), (verify, k)
+    for where in (0, L - 25, L - 1):  # an undefined byte in the far part, at its end, in the tail
+        bad = q2d.copy()
+        bad[4321, where] = ord("$")
+        with pytest.raises(AwryError) as e:
+            ix.parallel_count_csr(*synth.fixed_to_csr(bad))
+        assert e.value.code == ERR_INVALID_QUERY and "query 4321" in str(e.value)
+
+
+@pytest.mark.parametrize("lo,hi", [(1, 40), (8, 24), (5, 13), (20, 130), (900, 1030)])
 def test_amino_kmer_schedule_with_unequal_lengths(oracle, lo, hi):
     """amino batches of unequal lengths take the same two-phase schedule with per-query lengths (residues from the text,
     random ones, X / unknown letters, lower case; lengths below the seed length and above 24 residues are listed for the
@@ -1346,21 +1401,23 @@ def test_amino_kmer_schedule_with_unequal_lengths(oracle, lo, hi):
     import torch
     text, st, hd = synth.make_text(300000, 1, 93, 30, 0.02)
     text = text.copy()
-    text[150000:151000] = text[3000:4000]
+    dup = 1000 if hi <= 200 else 3000
+    text[150000:150000 + dup] = text[3000:3000 + dup]
     ix = gpu_index(text, 1, 8, 0, st, hd)
     oi = oracle.OracleIndex.from_text(text, 1, 8, 0, st, hd)
     rng = np.random.default_rng(lo * 100 + hi)
-    nq = 24000
+    nq = 24000 if hi <= 200 else 6000
     lens = rng.integers(lo, hi + 1, size=nq)
     qo = np.zeros(nq + 1, dtype=np.uint64)
     qo[1:] = np.cumsum(lens)
     starts = rng.integers(0, len(text) - hi - 2, size=nq)
     starts[: nq // 8] = rng.integers(3000, 3900, size=nq // 8)
+    starts[nq // 8: nq // 8 + 10] = np.arange(10)  # windows at the very beginning of the text
     idx = np.repeat(starts, lens) + (np.arange(int(qo[-1])) - np.repeat(qo[:-1].astype(np.int64), lens))
     qb = text[idx].copy()
     rmask = np.repeat(rng.random(nq) < 0.4, lens)
     qb[rmask] = synth.AA[rng.integers(0, 20, size=int(rmask.sum()))]
-    odd = rng.random(len(qb)) < 0.004
+    odd = rng.random(len(qb)) < min(0.004, 0.3 / hi)
     qb[odd] = np.frombuffer(b"XBZJ7*", dtype=np.uint8)[rng.integers(0, 6, size=int(odd.sum()))]
     qb[qb == ord("$")] = ord("A")
     low = np.repeat(rng.random(nq) < 0.1, lens)

@@ -204,8 +204,9 @@ int awry_dev_count_ascii(awry_index_t *idx, int slot, const void *d_qbytes, cons
                          void *d_counts, void *d_ranges, void *d_status, void *stream);
 /* n ASCII queries of `len` bytes each, back to back (no offsets) -> counts[n], optional status[n].  Nucleotide
  * indexes: packed on the device and served by the packed kernels (queries with letters outside ACGT are redone by the
- * generic kernel).  Amino k-mers of 8..24 residues: a two-phase schedule of their own (one query per lane against the
- * seed table and the text, the generic kernel on the few it cannot decide).  Every other shape: the generic kernel
+ * generic kernel).  Amino queries of 8..1024 residues: a two-phase schedule of their own (one query per lane against the
+ * seed table and the text -- the last 24 residues in registers, the rest compared with the text for surviving candidates --
+ * and the generic kernel on the few it cannot decide).  Every other shape: the generic kernel
  * reading query q at q * len.  Scratch lives in the replica, per stream. */
 int awry_dev_count_ascii_uniform(awry_index_t *idx, int slot, const void *d_qbytes, uint64_t n, uint64_t len,
                                  void *d_counts, void *d_status, void *stream);

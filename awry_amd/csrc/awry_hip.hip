@@ -16,6 +16,7 @@
 #include <memory>
 #include <mutex>
 #include <new>
+#include <set>
 #include <stdexcept>
 #include <string>
 #include <thread>
@@ -183,6 +184,11 @@ struct Replica {
   DevBuf<uint64_t> blocks, sa_words, seq_starts;
   DevBuf<SeedEntry> seed;
   DevBuf<SeedEntry64> seed64;  // wide-row replicas (bwt_len >= 2^32, or forced): 16-byte entries
+  // seed tables for k-mers SHORTER than the main table's k ("rungs": one complete 4^L table per query length L that has
+  // been asked for, built on first use; a 12-mer is then answered by its entry instead of 12 LF steps)
+  std::map<int, DevBuf<SeedEntry>> rungs;
+  std::set<int> rungs_refused;  // lengths whose table did not fit the HBM budget when first asked for
+  std::mutex rung_mu;
   bool wide = false;           // 64-bit rows: wide kernels, no 32-bit accelerators
   DevBuf<uint32_t> text4;                     // 4-bit text for seed-and-verify (device-only accelerator)
   DevBuf<uint8_t> text8;                      // the text as symbol indices, for the generic kernel's verify (any alphabet)
@@ -217,7 +223,7 @@ struct Replica {
       for (auto& ls : lane_stream) if (ls) (void)hipStreamDestroy(ls);
       if (ev0) (void)hipEventDestroy(ev0);
       if (ev1) (void)hipEventDestroy(ev1);
-      blocks.reset(); sa_words.reset(); seq_starts.reset(); seed.reset(); seed64.reset(); dense_sa.reset(); text4.reset();
+      blocks.reset(); sa_words.reset(); seq_starts.reset(); seed.reset(); seed64.reset(); rungs.clear(); dense_sa.reset(); text4.reset();
       scratch.clear();
       sa_nblock.reset(); text8.reset();
     }
@@ -333,6 +339,63 @@ int default_seed_k(const HostIndex& h) {
   return k;
 }
 
+// the complete sigma^k table of (first row, count + BWT symbol of a singleton) entries for a 32-bit-row replica, built
+// level by level on the replica's own stream (see seed_extend_kernel); synchronous
+void build_seed_table(Replica& r, bool nt, int k, DevBuf<SeedEntry>& out) {
+  const uint64_t sigma = nt ? 4 : AA_SEED_SIGMA;
+  uint64_t nfinal = 1;
+  for (int j = 0; j < k; j++) nfinal *= sigma;
+  DevBuf<SeedEntry> a(nfinal), b(std::max<uint64_t>(sigma, nfinal / sigma));
+  // level j lands in `a` when (k - j) is even, so the last level is in `a`
+  SeedEntry* cur = ((k - 1) % 2 == 0) ? a.p : b.p;
+  if (nt) hipLaunchKernelGGL(seed_level1_kernel, dim3(1), dim3(256), 0, r.stream, r.dev, cur);
+  else hipLaunchKernelGGL(aa_seed_level1_kernel, dim3(1), dim3(256), 0, r.stream, r.dev, cur);
+  uint64_t nchild = sigma;
+  for (int j = 2; j <= k; j++) {
+    SeedEntry* nxt = ((k - j) % 2 == 0) ? a.p : b.p;
+    nchild *= sigma;
+    if (nt) hipLaunchKernelGGL(seed_extend_kernel, dim3(grid_for(r, nchild * 4, 256)), dim3(256), 0, r.stream, r.dev, cur, nxt, nchild);
+    else hipLaunchKernelGGL(aa_seed_extend_kernel, dim3(grid_for(r, nchild, 256)), dim3(256), 0, r.stream, r.dev, cur, nxt, nchild);
+    cur = nxt;
+  }
+  if (nt) hipLaunchKernelGGL(seed_finalize_kernel, dim3(grid_for(r, nfinal, 256)), dim3(256), 0, r.stream, r.dev, a.p, nfinal);
+  else hipLaunchKernelGGL(aa_seed_finalize_kernel, dim3(grid_for(r, nfinal, 256)), dim3(256), 0, r.stream, r.dev, a.p, nfinal);
+  HIP_CHECK(hipGetLastError());
+  HIP_CHECK(hipStreamSynchronize(r.stream));
+  out = std::move(a);
+}
+
+// The table for nucleotide k-mers of L < seed_k letters, built on first use and kept.  nullptr: not available (it does not
+// fit the HBM budget, or AWRY_SEED_RUNGS=0) -- the caller falls back to LF steps from the last letter.
+constexpr int SEED_RUNG_MIN = 6;  // shorter k-mers: a handful of LF steps over blocks that live in L2
+const SeedEntry* seed_rung(Replica& r, int L) {
+  static const bool off = getenv("AWRY_SEED_RUNGS") && !strcmp(getenv("AWRY_SEED_RUNGS"), "0");
+  if (off || r.wide || r.dev.alphabet != NUCLEOTIDE || L < SEED_RUNG_MIN || L > 16) return nullptr;
+  std::lock_guard<std::mutex> lock(r.rung_mu);
+  auto it = r.rungs.find(L);
+  if (it != r.rungs.end()) return it->second.p;
+  if (r.rungs_refused.count(L)) return nullptr;
+  size_t free_b = 0;
+  if (!hbm_budget(&free_b) || (double)(10ull << (2 * L)) > 0.5 * (double)free_b) {  // 8 B per entry + a quarter of that while building
+    r.rungs_refused.insert(L);
+    return nullptr;
+  }
+  int cur_dev = 0;
+  HIP_CHECK(hipGetDevice(&cur_dev));
+  if (cur_dev != r.device) HIP_CHECK(hipSetDevice(r.device));
+  DevBuf<SeedEntry> t;
+  try {
+    build_seed_table(r, true, L, t);
+  } catch (const HipError&) {  // (hipMalloc: the budget was an estimate)
+    (void)hipGetLastError();
+    r.rungs_refused.insert(L);
+    return nullptr;
+  }
+  const SeedEntry* p = t.p;
+  r.rungs.emplace(L, std::move(t));
+  return p;
+}
+
 // level-by-level seed table on the replica's device (see seed_extend_kernel)
 void build_seed(awry_index* ix, Replica& r, int k) {
   r.seed.reset();
@@ -369,27 +432,9 @@ void build_seed(awry_index* ix, Replica& r, int k) {
   }
   require(narrow(ix->host), "seed table needs an index with bwt_len < 2^32");
   const bool nt = ix->host.alphabet == NUCLEOTIDE;
-  const uint64_t sigma = nt ? 4 : AA_SEED_SIGMA;
   require(k <= (nt ? 17 : 7), "seed k-mer length must be <= 17 (nucleotide) / 7 (amino)");
-  uint64_t nfinal = 1;
-  for (int j = 0; j < k; j++) nfinal *= sigma;
-  DevBuf<SeedEntry> a(nfinal), b(std::max<uint64_t>(sigma, nfinal / sigma));
-  // level j lands in `a` when (k - j) is even, so the last level is in `a`
-  SeedEntry* cur = ((k - 1) % 2 == 0) ? a.p : b.p;
-  if (nt) hipLaunchKernelGGL(seed_level1_kernel, dim3(1), dim3(256), 0, r.stream, r.dev, cur);
-  else hipLaunchKernelGGL(aa_seed_level1_kernel, dim3(1), dim3(256), 0, r.stream, r.dev, cur);
-  uint64_t nchild = sigma;
-  for (int j = 2; j <= k; j++) {
-    SeedEntry* nxt = ((k - j) % 2 == 0) ? a.p : b.p;
-    nchild *= sigma;
-    if (nt) hipLaunchKernelGGL(seed_extend_kernel, dim3(grid_for(r, nchild * 4, 256)), dim3(256), 0, r.stream, r.dev, cur, nxt, nchild);
-    else hipLaunchKernelGGL(aa_seed_extend_kernel, dim3(grid_for(r, nchild, 256)), dim3(256), 0, r.stream, r.dev, cur, nxt, nchild);
-    cur = nxt;
-  }
-  if (nt) hipLaunchKernelGGL(seed_finalize_kernel, dim3(grid_for(r, nfinal, 256)), dim3(256), 0, r.stream, r.dev, a.p, nfinal);
-  else hipLaunchKernelGGL(aa_seed_finalize_kernel, dim3(grid_for(r, nfinal, 256)), dim3(256), 0, r.stream, r.dev, a.p, nfinal);
-  HIP_CHECK(hipGetLastError());
-  HIP_CHECK(hipStreamSynchronize(r.stream));
+  DevBuf<SeedEntry> a;
+  build_seed_table(r, nt, k, a);
   r.seed = std::move(a);
   r.seed_k = k;
   r.dev.seed = r.seed.p;
@@ -814,12 +859,18 @@ void launch_count_nt2(Replica& r, const uint64_t* d_words, uint64_t n, int L, ui
     HIP_CHECK(hipGetLastError());
     return;
   }
-  const bool seeded = use_seed && r.seed_k > 0 && r.seed_k <= L;
+  // k-mers shorter than the seed table's k: their own complete table ("rung", built on first use) -- the entry IS the
+  // answer, where LF steps from the last letter cost L dependent block reads (GRCh38 scale: 12-mers 5.6 -> 30+ G/s)
+  DevIndex dv = r.dev;
+  bool rung = false;
+  if (use_seed && r.seed_k > L && r.seed.p && n >= 4096 && n < (1ull << 32) && count_kernel_override() < 0)
+    if (const SeedEntry* t = seed_rung(r, L)) { dv.seed = t; dv.seed_k = L; dv.seed_pos = 0; dv.ctx_extra = 0; rung = true; }
+  const bool seeded = rung || (use_seed && r.seed_k > 0 && r.seed_k <= L);
   const dim3 g(grid_for(r, n * 4, 256)), b(256);
   // AWRY_COUNT_KERNEL=chunk selects the LDS-staged variant (count_nt2_chunk_kernel).  Measured on MI355X it is
   // equal at seed k=14 and 23% slower at k=16 (GRCh38-scale): the strided kernel's query words already arrive
   // as L2 hits, so staging only removes the partial-line result writes and pays chunk drain + refill for it.
-  const int kmode = count_kernel_mode(r.dev.bwt_len, r.seed_k, seeded);
+  const int kmode = rung ? 3 : count_kernel_mode(r.dev.bwt_len, r.seed_k, seeded);
   const bool use_chunk = kmode == 1;
   if (use_chunk) {
     unsigned long long* ctr = next_counter(r, s);
@@ -852,8 +903,8 @@ void launch_count_nt2(Replica& r, const uint64_t* d_words, uint64_t n, int L, ui
     const bool vfy = r.dev.text4 != nullptr && r.dev.dense_ratio == 1;
 #define AWRY_LAUNCH_TWO_PHASE(T, V)                                                                                 \
   do {                                                                                                             \
-    hipLaunchKernelGGL((count_nt2_probe_kernel<T, V>), gp, b, 0, s, r.dev, d_words, n, L, d_counts, sv, d_tally);  \
-    hipLaunchKernelGGL((count_nt2_resume_kernel<T, V>), gp, b, 0, s, r.dev, sv, L, d_counts, d_tally);             \
+    hipLaunchKernelGGL((count_nt2_probe_kernel<T, V>), gp, b, 0, s, dv, d_words, n, L, d_counts, sv, d_tally);     \
+    hipLaunchKernelGGL((count_nt2_resume_kernel<T, V>), gp, b, 0, s, dv, sv, L, d_counts, d_tally);                \
   } while (0)
     if (d_tally) { if (vfy) AWRY_LAUNCH_TWO_PHASE(true, true); else AWRY_LAUNCH_TWO_PHASE(true, false); }
     else { if (vfy) AWRY_LAUNCH_TWO_PHASE(false, true); else AWRY_LAUNCH_TWO_PHASE(false, false); }
@@ -2124,6 +2175,9 @@ const char* awry_count_schedule(const awry_index_t* idx, int L) {
     const bool two = r.dev.text4 && r.dev.dense_ratio == 1 && seeded && L - r.seed_k >= 3 && L <= 512 && (om < 0 || om == 3);
     return two ? "count_nt2_reads_probe_kernel+count_nt2_reads_kernel" : "count_nt2_reads_kernel";
   }
+  static const bool rungs_off = getenv("AWRY_SEED_RUNGS") && !strcmp(getenv("AWRY_SEED_RUNGS"), "0");
+  if (!seeded && r.seed_k > L && L >= SEED_RUNG_MIN && !rungs_off && count_kernel_override() < 0)
+    return "count_nt2_probe_kernel+count_nt2_resume_kernel (table of its own for this length; batches of 4096 queries and more)";
   int m = count_kernel_mode(r.dev.bwt_len, r.seed_k, seeded);
   if (m == 3 && !seeded) m = 2;
   return names[m & 3];

@@ -77,7 +77,9 @@ void awry_free(awry_index_t *idx);
  * sharded contiguously over the replicas.  n_devices == 0 is an error: there is no CPU backend.  Replaces (and first
  * releases) any earlier replicas.  HBM use: the default policies size the seed table to 70 % of the free HBM and keep
  * the locate / verify accelerators (7 B per text symbol) when they fit in half of it -- ~160 GB for a GRCh38-scale
- * index; AWRY_HBM_BUDGET_GB caps the figure they plan with, AWRY_SEED_K / AWRY_VERIFY=0 pin the choices. */
+ * index; AWRY_HBM_BUDGET_GB caps the figure they plan with, AWRY_SEED_K / AWRY_VERIFY=0 pin the choices.  Later, the first
+ * batch of >= 4096 nucleotide k-mers of a length L below the seed table's k adds a complete 4^L table for that length
+ * (8 B x 4^L: 134 MB for L = 12, 34 GB for L = 16) when it fits half of the free HBM; AWRY_SEED_RUNGS=0 turns that off. */
 int awry_set_devices(awry_index_t *idx, const int *device_ids, int n_devices);
 /* device-side seed-table length (performance knob only; results do not depend on it).  0 disables,
  * -1 picks the default.  Takes effect immediately on all replicas. */

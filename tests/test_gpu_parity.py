@@ -285,6 +285,30 @@ def test_automatic_gpu_construction_falls_back_to_the_host(monkeypatch):
     assert (auto.parallel_count_csr(*synth.fixed_to_csr(q)) >= 1).all()
 
 
+@pytest.mark.parametrize("L", [6, 7, 9, 10])
+def test_kmers_shorter_than_the_seed_table(oracle, L):
+    """k-mers shorter than the seed table's k get a complete table of their own length on first use (a "rung": the entry is
+    the answer); counts and locations against the oracle, device-resident and through the host path, and equal to plain
+    backward search (no table); a small batch (no rung) gives the same"""
+    import torch
+    text, st, hd = synth.make_text(1_000_000, 0, 33, 3, 0.02)
+    ix = gpu_index(text, 0, 8, 0, st, hd)
+    assert ix.seed_kmer_len() > L and "table of its own" in ix.count_schedule(L)
+    oi = oracle.OracleIndex.from_text(text, 0, 8, 0, st, hd)
+    q2d = np.concatenate([synth.sampled_queries(text, 15000, L, L), synth.random_queries(15000, L, 0, L + 1)])
+    qb, qo = synth.fixed_to_csr(q2d)
+    want, _ = oi.parallel_count(qb, qo, 4)
+    assert np.array_equal(ix.count_kmers_nt2(q2d, True), want)       # device-resident, rung table
+    assert np.array_equal(ix.count_kmers_nt2(q2d, False), want)      # no table at all
+    assert np.array_equal(ix.count_kmers_nt2(q2d[:100], True), want[:100])
+    assert np.array_equal(ix.parallel_count_csr(qb, qo), want)       # host path
+    sub = slice(0, 300)
+    qb2, qo2 = synth.fixed_to_csr(q2d[sub])
+    ooff, ogpos, opos, _ = oi.parallel_locate(qb2, qo2, 4)
+    off, gpos, pos = ix.parallel_locate_csr(qb2, qo2)
+    assert np.array_equal(off, ooff) and np.array_equal(gpos, ogpos) and np.array_equal(pos, opos)
+
+
 def test_genome_like_text_construction_and_repeats(oracle):
     """a chromosome-shaped text (megabase N gaps, satellite array, exact tandem array, segmental duplications,
     synth.genome_like_text): the GPU construction needs ~15 doubling rounds and stays bit-identical to host SA-IS, and

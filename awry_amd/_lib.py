@@ -112,6 +112,7 @@ def load_library():
     sig("awry_dev_count_nt2", i32, vp, i32, vp, u64, i32, vp, i32, vp)
     sig("awry_dev_count_nt2_tally", i32, vp, i32, vp, u64, i32, vp, i32, vp, vp)
     sig("awry_dev_count_ascii", i32, vp, i32, vp, vp, u64, vp, vp, vp, vp)
+    sig("awry_dev_count_ascii_for_locate", i32, vp, i32, vp, vp, u64, vp, vp, vp, vp)
     sig("awry_dev_count_ascii_uniform", i32, vp, i32, vp, u64, u64, vp, vp, vp)
     sig("awry_dev_count_ascii_uniform_tally", i32, vp, i32, vp, u64, u64, vp, vp, vp)
     sig("awry_dev_scan_scratch_bytes", u64, u64)

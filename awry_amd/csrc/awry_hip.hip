@@ -2572,6 +2572,16 @@ int awry_dev_count_ascii(awry_index_t* idx, int slot, const void* d_qbytes, cons
   });
 }
 
+int awry_dev_count_ascii_for_locate(awry_index_t* idx, int slot, const void* d_qbytes, const void* d_qoff, uint64_t n, void* d_counts,
+                                    void* d_locate_words, void* d_status, void* stream) {
+  return guarded([&] {
+    Replica& r = replica(idx, slot);
+    require((d_qoff && d_counts && d_locate_words) || n == 0, "null device pointer");
+    launch_count_ascii(r, (const uint8_t*)d_qbytes, (const uint64_t*)d_qoff, n, (uint64_t*)d_counts, (uint64_t*)d_locate_words,
+                       (uint8_t*)d_status, (hipStream_t)stream, true);  // RS_* words where the count pass verified against the text
+  });
+}
+
 int awry_dev_count_ascii_uniform(awry_index_t* idx, int slot, const void* d_qbytes, uint64_t n, uint64_t len, void* d_counts,
                                  void* d_status, void* stream) {
   return guarded([&] {

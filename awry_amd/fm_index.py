@@ -388,6 +388,10 @@ class FmIndex:
     def dev_count_ascii(self, d_qbytes, d_qoff, n, d_counts, d_ranges=None, d_status=None, stream=None, slot=0):
         _check(self._L.awry_dev_count_ascii(self._h, slot, d_qbytes, d_qoff, n, d_counts, d_ranges, d_status, stream))
 
+    def dev_count_ascii_for_locate(self, d_qbytes, d_qoff, n, d_counts, d_locate_words, d_status=None, stream=None, slot=0):
+        """count pass of a device-resident parallel_locate: d_locate_words[2n] are opaque words for dev_locate (range_stride 2)"""
+        _check(self._L.awry_dev_count_ascii_for_locate(self._h, slot, d_qbytes, d_qoff, n, d_counts, d_locate_words, d_status, stream))
+
     def dev_count_ascii_uniform(self, d_qbytes, n, length, d_counts, d_status=None, stream=None, slot=0):
         """n ASCII queries of `length` bytes each, back to back (amino k-mers: the two-phase schedule)"""
         _check(self._L.awry_dev_count_ascii_uniform(self._h, slot, d_qbytes, n, length, d_counts, d_status, stream))

@@ -204,6 +204,12 @@ int awry_dev_count_nt2_tally(awry_index_t *idx, int slot, const void *d_words, u
 /* generic path: ASCII queries + u64 offsets[n+1] -> counts[n], optional ranges[2n] (start,end) and status[n] bytes */
 int awry_dev_count_ascii(awry_index_t *idx, int slot, const void *d_qbytes, const void *d_qoff, uint64_t n,
                          void *d_counts, void *d_ranges, void *d_status, void *stream);
+/* the count pass of a device-resident parallel_locate: as above, but d_locate_words[2n] receives what awry_dev_locate
+ * (range_stride 2) needs per query -- a row interval, or the text position(s) the count pass already verified when the
+ * seed-and-verify accelerators are resident -- instead of row intervals, which lets the fast schedules run (amino k-mers:
+ * 10x the rate of awry_dev_count_ascii with ranges).  The words are opaque: feed them to awry_dev_locate, nothing else. */
+int awry_dev_count_ascii_for_locate(awry_index_t *idx, int slot, const void *d_qbytes, const void *d_qoff, uint64_t n,
+                                    void *d_counts, void *d_locate_words, void *d_status, void *stream);
 /* n ASCII queries of `len` bytes each, back to back (no offsets) -> counts[n], optional status[n].  Nucleotide
  * indexes: packed on the device and served by the packed kernels (queries with letters outside ACGT are redone by the
  * generic kernel).  Amino queries of 8..1024 residues: a two-phase schedule of their own (one query per lane against the

@@ -309,6 +309,50 @@ def test_kmers_shorter_than_the_seed_table(oracle, L):
     assert np.array_equal(off, ooff) and np.array_equal(gpos, ogpos) and np.array_equal(pos, opos)
 
 
+@pytest.mark.parametrize("alphabet", [0, 1])
+def test_device_resident_locate_pipeline_from_ascii(oracle, alphabet):
+    """awry_dev_count_ascii_for_locate -> awry_dev_scan_counts -> awry_dev_locate, all on caller-owned device buffers:
+    the oracle's offsets, text positions and (record, offset) pairs, with the accelerators on (verified positions in the
+    locate words) and off (row intervals)"""
+    import torch
+    text, st, hd = synth.make_text(400000, alphabet, 17, 6, 0.01 if alphabet == 0 else 0.0)
+    ix = gpu_index(text, alphabet, 8, 0, st, hd)
+    oi = oracle.OracleIndex.from_text(text, alphabet, 8, 0, st, hd)
+    rng = np.random.default_rng(3)
+    nq = 20000
+    lens = rng.integers(9, 41, size=nq)
+    qo = np.zeros(nq + 1, dtype=np.uint64); qo[1:] = np.cumsum(lens)
+    starts = rng.integers(0, len(text) - 45, size=nq)
+    idx = np.repeat(starts, lens) + (np.arange(int(qo[-1])) - np.repeat(qo[:-1].astype(np.int64), lens))
+    qb = text[idx].copy()
+    qb[qb == ord("$")] = ord("A")
+    rmask = np.repeat(rng.random(nq) < 0.3, lens)
+    letters = synth.NT if alphabet == 0 else synth.AA
+    qb[rmask] = letters[rng.integers(0, len(letters), size=int(rmask.sum()))]
+    ooff, ogpos, opos, _ = oi.parallel_locate(qb, qo, 4)
+    dev = torch.device("cuda", 0); stream = torch.cuda.current_stream().cuda_stream
+    d_q = torch.from_numpy(np.concatenate([qb, np.zeros(16, dtype=np.uint8)])).to(dev)
+    d_off = torch.from_numpy(qo.astype(np.int64)).to(dev)
+    for verify in (2, -1):
+        ix.set_verify(verify)
+        d_c = torch.zeros(nq, dtype=torch.int64, device=dev); d_w = torch.zeros(2 * nq, dtype=torch.int64, device=dev)
+        d_s = torch.full((nq,), 9, dtype=torch.uint8, device=dev)
+        d_ho = torch.zeros(nq + 1, dtype=torch.int64, device=dev)
+        d_sc = torch.zeros(ix.dev_scan_scratch_bytes(nq) // 8 + 8, dtype=torch.int64, device=dev)
+        ix.dev_count_ascii_for_locate(d_q.data_ptr(), d_off.data_ptr(), nq, d_c.data_ptr(), d_w.data_ptr(), d_s.data_ptr(), stream, 0)
+        ix.dev_scan_counts(d_c.data_ptr(), nq, d_ho.data_ptr(), d_sc.data_ptr(), stream, 0)
+        torch.cuda.synchronize()
+        assert int(d_s.max()) == 0
+        off = d_ho.cpu().numpy().astype(np.uint64)
+        assert np.array_equal(off, ooff)
+        total = int(off[-1])
+        d_g = torch.zeros(total, dtype=torch.int64, device=dev); d_p = torch.zeros(2 * total, dtype=torch.int64, device=dev)
+        ix.dev_locate(d_w.data_ptr(), d_ho.data_ptr(), nq, total, d_g.data_ptr(), d_p.data_ptr(), stream, 0)
+        torch.cuda.synchronize()
+        assert np.array_equal(d_g.cpu().numpy().astype(np.uint64), ogpos), verify
+        assert np.array_equal(d_p.cpu().numpy().astype(np.uint64).reshape(-1, 2), opos), verify
+
+
 def test_genome_like_text_construction_and_repeats(oracle):
     """a chromosome-shaped text (megabase N gaps, satellite array, exact tandem array, segmental duplications,
     synth.genome_like_text): the GPU construction needs ~15 doubling rounds and stays bit-identical to host SA-IS, and

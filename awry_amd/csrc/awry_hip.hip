@@ -182,6 +182,7 @@ struct Replica {
   std::mutex mailbox_mu;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   DevBuf<uint64_t> blocks, sa_words, seq_starts;
+  DevBuf<uint32_t> seq_bucket;  // DevIndex::seq_bucket (indexes of more records than the locate kernels keep in LDS)
   DevBuf<SeedEntry> seed;
   DevBuf<SeedEntry64> seed64;  // wide-row replicas (bwt_len >= 2^32, or forced): 16-byte entries
   // seed tables for k-mers SHORTER than the main table's k ("rungs": one complete 4^L table per query length L that has
@@ -518,6 +519,29 @@ std::unique_ptr<Replica> make_replica(awry_index* ix, int device) {
   d.sa_words = r->sa_words.p;
   d.seed = nullptr;
   d.seq_starts = r->seq_starts.p;
+  d.seq_bucket = nullptr;
+  d.seq_bucket_shift = d.seq_bucket_pad = 0;
+  if (h.seq_starts.size() > (size_t)LOC_SEQ_LDS && h.seq_starts.size() < (1ull << 32)) {
+    // about four buckets per record (at most 2^22): a position's record is then one of the one or two its bucket touches
+    const uint64_t nseq = h.seq_starts.size();
+    uint64_t want = 1;
+    while (want < 4 * nseq && want < (1ull << 22)) want <<= 1;
+    uint32_t shift = 0;
+    while ((((h.bwt_len - 1) >> shift) + 1) > want) shift++;
+    const uint64_t nb = ((h.bwt_len - 1) >> shift) + 1;
+    std::vector<uint32_t> tab(nb + 1);
+    uint64_t rec = 0;
+    for (uint64_t b = 0; b < nb; b++) {
+      const uint64_t p0 = b << shift;
+      while (rec + 1 < nseq && h.seq_starts[rec + 1] <= p0) rec++;
+      tab[b] = (uint32_t)rec;
+    }
+    tab[nb] = (uint32_t)(nseq - 1);
+    r->seq_bucket.alloc(nb + 1);
+    HIP_CHECK(hipMemcpy(r->seq_bucket.p, tab.data(), (nb + 1) * 4, hipMemcpyHostToDevice));
+    d.seq_bucket = r->seq_bucket.p;
+    d.seq_bucket_shift = shift;
+  }
   d.nblocks = h.nblocks;
   d.bwt_len = h.bwt_len;
   d.sentinel_row = h.sentinel_row;

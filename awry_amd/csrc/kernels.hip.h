@@ -2137,6 +2137,11 @@ constexpr uint64_t LOC_WALK_FLAG = 1ull << 63;  // gpos[h] holds a BWT row that 
 // src/sequence_index.rs:108-141, see SURVEY a-17)
 __device__ __forceinline__ void localise(const DevIndex& ix, uint64_t g, uint64_t* __restrict__ out) {
   uint64_t a = 0, z = ix.nseq;
+  if (ix.seq_bucket) {  // the records of g's bucket: from the one holding the bucket's first position to the one holding the next bucket's
+    const uint64_t b = g >> ix.seq_bucket_shift;
+    a = ix.seq_bucket[b];
+    z = (uint64_t)ix.seq_bucket[b + 1] + 1;
+  }
   while (z - a > 1) { uint64_t mid = (a + z) >> 1; if (ix.seq_starts[mid] <= g) a = mid; else z = mid; }
   out[0] = a;
   out[1] = g - (ix.nseq ? ix.seq_starts[a] : 0);

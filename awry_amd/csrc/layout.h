@@ -133,6 +133,11 @@ struct DevIndex {
   const SeedEntry* seed;      // sigma^seed_k entries or nullptr (indexes below 2^32 rows)
   const SeedEntry64* seed64;  // 4^seed_k entries of a wide-row nucleotide index, or nullptr
   const uint64_t* seq_starts; // nseq record start offsets
+  // indexes of many records (protein databases, contig-level assemblies): seq_bucket[b] = the record that holds text
+  // position b << seq_bucket_shift, so that a position's record is found among the few records of its bucket instead of
+  // by ~20 dependent loads over all record starts; nullptr when the record starts fit the locate kernels' LDS copy
+  const uint32_t* seq_bucket;
+  uint32_t seq_bucket_shift, seq_bucket_pad;
   uint64_t nblocks, bwt_len, sentinel_row, nseq;
   uint64_t prefix_sums[24];   // C[i], src/fm_index.rs:233-240
   uint32_t sa_bits, sa_ratio;

@@ -309,13 +309,14 @@ def test_kmers_shorter_than_the_seed_table(oracle, L):
     assert np.array_equal(off, ooff) and np.array_equal(gpos, ogpos) and np.array_equal(pos, opos)
 
 
-@pytest.mark.parametrize("alphabet", [0, 1])
-def test_device_resident_locate_pipeline_from_ascii(oracle, alphabet):
+@pytest.mark.parametrize("alphabet,records", [(0, 6), (1, 6), (0, 7000), (1, 3000)])
+def test_device_resident_locate_pipeline_from_ascii(oracle, alphabet, records):
     """awry_dev_count_ascii_for_locate -> awry_dev_scan_counts -> awry_dev_locate, all on caller-owned device buffers:
     the oracle's offsets, text positions and (record, offset) pairs, with the accelerators on (verified positions in the
-    locate words) and off (row intervals)"""
+    locate words) and off (row intervals: hits walk to a sample and are localised afterwards); with a handful of records
+    (their starts sit in LDS) and with thousands (contigs, proteins: a bucket table narrows the search, DevIndex::seq_bucket)"""
     import torch
-    text, st, hd = synth.make_text(400000, alphabet, 17, 6, 0.01 if alphabet == 0 else 0.0)
+    text, st, hd = synth.make_text(400000, alphabet, 17, records, 0.01 if alphabet == 0 else 0.0)
     ix = gpu_index(text, alphabet, 8, 0, st, hd)
     oi = oracle.OracleIndex.from_text(text, alphabet, 8, 0, st, hd)
     rng = np.random.default_rng(3)
@@ -351,6 +352,8 @@ def test_device_resident_locate_pipeline_from_ascii(oracle, alphabet):
         torch.cuda.synchronize()
         assert np.array_equal(d_g.cpu().numpy().astype(np.uint64), ogpos), verify
         assert np.array_equal(d_p.cpu().numpy().astype(np.uint64).reshape(-1, 2), opos), verify
+        got = ix.parallel_locate_csr(qb, qo)
+        assert np.array_equal(got[0], ooff) and np.array_equal(got[1], ogpos) and np.array_equal(got[2], opos), verify
 
 
 def test_genome_like_text_construction_and_repeats(oracle):

@@ -21,6 +21,8 @@ for trial in range(trials):
     alphabet = 1 if only_aa else int(rng.integers(0, 2))
     n = int(rng.choice([300, 3000, 20000, 200000] if only_aa else [5, 40, 300, 3000, 20000, 200000]))
     recs = int(min(max(1, n // 50), rng.integers(1, 9)))
+    if n >= 20000 and rng.random() < 0.2:  # thousands of records: the locate kernels' bucket table over the record starts
+        recs = int(rng.integers(1100, 3000))
     nfrac = float(rng.choice([0.0, 0.02, 0.3])) if alphabet == 0 else 0.0
     ratio = int(rng.choice([1, 3, 8, 16]))
     text, st, hd = synth.make_text(n, alphabet, int(rng.integers(1, 1 << 30)), recs if n >= 40 else 1, nfrac)
@@ -37,6 +39,8 @@ for trial in range(trials):
     mode = int(rng.integers(0, 3))  # 0 fixed length, 1 ragged, 2 ragged with ambiguity letters / lower case
     nq = int(rng.choice([1, 70, 5000, 30000, 70000], p=[0.24, 0.24, 0.24, 0.2, 0.08]))  # 70000: above the host path's assumed-uniform threshold
     Lfix = int(rng.integers(1, min(120, n) + 1))
+    if n >= 3000 and rng.random() < 0.15:  # long queries: amino LONG pass, multi-word reads
+        Lfix = int(rng.integers(121, 700))
     if only_aa:
         mode, nq, Lfix = 0, int(rng.choice([5000, 12000])), int(rng.integers(6, 27))
     qs = []

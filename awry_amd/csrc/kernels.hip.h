@@ -1316,7 +1316,7 @@ __global__ __launch_bounds__(256) void count_nt2_probe_kernel(DevIndex ix, const
           const uint32_t nc = (uint32_t)(w >> (2 * (i0 - 1))) & 3u;
           survivor = seed_sym(e) == (int)(nc == 3u ? 5u : nc + 1u);  // else BWT[sp] is not the next letter: absent
           if (verify && survivor) { queued = true; survivor = false; }
-        } else if (verify && cnt <= (uint32_t)VMULTI && (int)(3u * cnt) <= i0) {
+        } else if (verify && cnt <= (uint32_t)VMULTI && (int)(3u * cnt) <= i0 + 2) {  // (+ 2: two rows with 4 or 5 letters left are cheaper here than as survivors)
           queued = true;  // a handful of candidate rows: each is checked against the text here, none goes to phase 2
         } else survivor = true;
         if (!queued) counts[q] = value;  // coalesced; survivors are overwritten by phase 2

@@ -262,7 +262,9 @@ bool pack_nt2_host(const uint8_t* ascii, const uint8_t* ascii_end, const uint64_
   std::mutex bad_mu;
   std::atomic<int> uneven{0};
   const uint64_t base = off ? off[lo] : 0;
-  HostPool::instance().run_ranges(n, 8192, [&](uint64_t a, uint64_t b) {
+  // waking the pool costs ~40 us (its workers sleep between jobs): a batch one thread packs faster than that stays here
+  const uint64_t grain = n * W <= 16384 ? n : 8192;
+  HostPool::instance().run_ranges(n, grain, [&](uint64_t a, uint64_t b) {
     uint32_t local[64];
     int nl = 0;
     auto flush = [&] {

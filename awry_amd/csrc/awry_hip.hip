@@ -328,12 +328,15 @@ int default_seed_k(const HostIndex& h) {
       while (k > 1 && 8.5 * std::pow((double)AA_SEED_SIGMA, k) > 0.7 * (double)free_b) k--;
     return k;
   }
-  // Several table entries per suffix: k = floor(log4 bwt_len) + 2, i.e. 4^k = 4..16 x bwt_len (GRCh38: k = 17, 137 GB of
-  // the 288 GB HBM; chr1: 15, 8.6 GB; E. coli: 13).  A random k-mer's entry is then empty or a singleton whose BWT
-  // symbol rarely matches, so a query costs one probe plus ~0.1 steps instead of ~16 steps (27 block reads).  The
-  // table and its build scratch (1/4 of it) must fit in 70 % of the free HBM, else k drops.
-  int k = (int)std::floor(std::log((double)h.bwt_len) / std::log(4.0)) + 2;
-  k = std::max(1, std::min(k, 17));
+  // A dozen table entries per suffix or more: the smallest k with 4^k >= 12 x bwt_len, at most 17 (GRCh38: 17, 137 GB of the
+  // 288 GB HBM and 5.5 entries per suffix -- 18 would not fit; chr1: 16, 34 GB; E. coli: 13).  A random k-mer's entry is
+  // then empty or a singleton whose BWT symbol rarely matches, so a query costs one probe plus ~0.1 steps instead of ~16
+  // steps (27 block reads), and a k-mer from the text rarely shares its seed with another one.  (Round 1 took
+  // floor(log4 bwt_len) + 2, i.e. 4..16 entries per suffix; chr1 sat at the low end of that with k = 15: k = 16 counts
+  // random 31-mers 8 %, 31-mers from the text 36 % and 101-bp reads 18 % faster.)  The table and its build scratch (1/4 of
+  // it) must fit in 70 % of the free HBM, else k drops.
+  int k = 1;
+  while (k < 17 && (double)(1ull << (2 * k)) < 12.0 * (double)h.bwt_len) k++;
   size_t free_b = 0;
   if (hbm_budget(&free_b))
     while (k > 1 && (double)(10ull << (2 * k)) > 0.7 * (double)free_b) k--;  // 8 B + 2 B scratch per entry

@@ -1001,13 +1001,13 @@ def test_all_count_kernel_schedules_agree(oracle):
 
 
 def test_default_device_policies():
-    """awry_set_devices picks the accelerators by itself: seed k = floor(log4 n) + 2, seed-and-verify structures resident
+    """awry_set_devices picks the accelerators by itself: the smallest seed k with 4^k >= 12 n, seed-and-verify structures resident
     for reads; the k-mer kernel leaves verify off unless asked; everything can be switched off again"""
     text, st, hd = synth.make_text(1_000_000, 0, 3, 1, 0.02)
     ix = gpu_index(text, 0, 8, 0, st, hd)
-    assert ix.seed_kmer_len() == 11            # floor(log4(1e6)) = 9, + 2
+    assert ix.seed_kmer_len() == 12            # 4^12 = 1.7e7 >= 1.2e7 > 4^11
     assert ix.verify_enabled() and ix.locate_sa_ratio() == 1
-    assert "probe" in ix.count_schedule(31)    # 4^11 >= 3 n: two-phase
+    assert "probe" in ix.count_schedule(31)    # 4^12 >= 3 n: two-phase
     ix.set_seed_kmer_len(8)
     assert ix.count_schedule(31) == "count_nt2_quad4_kernel" and ix.count_schedule(5) == "count_nt2_quad4_kernel"
     ix.set_verify(-1)

@@ -379,14 +379,20 @@ const SeedEntry* seed_rung(Replica& r, int L) {
   auto it = r.rungs.find(L);
   if (it != r.rungs.end()) return it->second.p;
   if (r.rungs_refused.count(L)) return nullptr;
+  // 8 B per entry + a quarter of that while building must fit half of what is free now (AWRY_HBM_BUDGET_GB caps that figure),
+  // and all rungs of a replica together stay below AWRY_SEED_RUNG_GB (default 48: every length 6..16 at once would be 46 GB)
+  static const double rung_cap = [] { const char* e = getenv("AWRY_SEED_RUNG_GB"); return (e && atof(e) > 0 ? atof(e) : 48.0) * 1e9; }();
+  double held = 0;
+  for (const auto& kv : r.rungs) held += 8.0 * (double)kv.second.n;
   size_t free_b = 0;
-  if (!hbm_budget(&free_b) || (double)(10ull << (2 * L)) > 0.5 * (double)free_b) {  // 8 B per entry + a quarter of that while building
+  if (!hbm_budget(&free_b) || (double)(10ull << (2 * L)) > 0.5 * (double)free_b || held + (double)(8ull << (2 * L)) > rung_cap) {
     r.rungs_refused.insert(L);
     return nullptr;
   }
   int cur_dev = 0;
   HIP_CHECK(hipGetDevice(&cur_dev));
   if (cur_dev != r.device) HIP_CHECK(hipSetDevice(r.device));
+  struct Restore { int dev, mine; ~Restore() { if (dev != mine) (void)hipSetDevice(dev); } } restore{cur_dev, r.device};  // the caller's device
   DevBuf<SeedEntry> t;
   try {
     build_seed_table(r, true, L, t);
@@ -637,9 +643,13 @@ void launch_aa_two_phase(Replica& r, const uint8_t* d_q, const uint64_t* d_off, 
 
 // allow_verify: the generic kernel may finish queries against the text (ranges then hold RS_* words for locate, not rows)
 // ulen != 0: n queries of ulen bytes each, back to back (d_off is not read)
+// ref_kmer_len >= 0: the reference's own step schedule with that lookup_table_kmer_len -- no seed table, kmer_len - 1 steps taken
+// unconditionally (src/fm_index.rs:402-438, src/kmer_lookup_table.rs:90-110): what awry_search_range returns, rows of absent queries included
 void launch_count_ascii(Replica& r, const uint8_t* d_q, const uint64_t* d_off, uint64_t n, uint64_t* d_counts,
-                        uint64_t* d_ranges, uint8_t* d_status, hipStream_t s, bool allow_verify, uint64_t ulen = 0) {
+                        uint64_t* d_ranges, uint8_t* d_status, hipStream_t s, bool allow_verify, uint64_t ulen = 0, int ref_kmer_len = -1) {
   if (n == 0) return;
+  const int vmode = ref_kmer_len >= 0 ? (2 | (ref_kmer_len << 8)) : (allow_verify ? 1 : 0);
+  if (ref_kmer_len >= 0) allow_verify = false;
   static const bool aa_off = getenv("AWRY_AA_KMER") && !strcmp(getenv("AWRY_AA_KMER"), "0");
   if (r.dev.alphabet == AMINO && allow_verify && !ulen && d_off && r.seed_k >= 1 && n >= 4096 && n < (1ull << 32) && !aa_off) {
     // amino batches of any lengths: the k-mer schedule with per-query lengths (queries it does not take are listed)
@@ -649,9 +659,9 @@ void launch_count_ascii(Replica& r, const uint8_t* d_q, const uint64_t* d_off, u
   const dim3 g(grid_for(r, n, 256)), b(256);
   const QueryList none{};
   if (r.dev.alphabet == NUCLEOTIDE)
-    hipLaunchKernelGGL((count_scalar_kernel<NUCLEOTIDE, LIST_NONE>), g, b, 0, s, r.dev, d_q, d_off, n, d_counts, d_ranges, d_status, allow_verify ? 1 : 0, ulen, none);
+    hipLaunchKernelGGL((count_scalar_kernel<NUCLEOTIDE, LIST_NONE>), g, b, 0, s, r.dev, d_q, d_off, n, d_counts, d_ranges, d_status, vmode, ulen, none);
   else
-    hipLaunchKernelGGL((count_scalar_kernel<AMINO, LIST_NONE>), g, b, 0, s, r.dev, d_q, d_off, n, d_counts, d_ranges, d_status, allow_verify ? 1 : 0, ulen, none);
+    hipLaunchKernelGGL((count_scalar_kernel<AMINO, LIST_NONE>), g, b, 0, s, r.dev, d_q, d_off, n, d_counts, d_ranges, d_status, vmode, ulen, none);
   HIP_CHECK(hipGetLastError());
 }
 
@@ -997,7 +1007,7 @@ struct ChunkBuffers {
 
 // upload one chunk and run the generic count kernel; leaves counts / ranges / status on the device
 void run_count_chunk(Replica& r, ChunkBuffers& cb, const uint8_t* qbytes, const uint64_t* qoff, Shard c, bool want_ranges,
-                     bool allow_verify = true) {
+                     bool allow_verify = true, int ref_kmer_len = -1) {
   const uint64_t n = c.hi - c.lo, base = qoff[c.lo], nbytes = qoff[c.hi] - base;
   cb.h_off.resize(n + 1);
   for (uint64_t i = 0; i <= n; i++) {
@@ -1011,7 +1021,7 @@ void run_count_chunk(Replica& r, ChunkBuffers& cb, const uint8_t* qbytes, const 
   if (want_ranges && cb.ranges.n < 2 * n) cb.ranges.alloc(2 * n);
   if (nbytes) HIP_CHECK(hipMemcpyAsync(cb.q.p, qbytes + base, nbytes, hipMemcpyHostToDevice, r.stream));
   HIP_CHECK(hipMemcpyAsync(cb.off.p, cb.h_off.data(), (n + 1) * 8, hipMemcpyHostToDevice, r.stream));
-  launch_count_ascii(r, cb.q.p, cb.off.p, n, cb.counts.p, want_ranges ? cb.ranges.p : nullptr, cb.status.p, r.stream, allow_verify);
+  launch_count_ascii(r, cb.q.p, cb.off.p, n, cb.counts.p, want_ranges ? cb.ranges.p : nullptr, cb.status.p, r.stream, allow_verify, 0, ref_kmer_len);
   cb.h_status.resize(n);
   HIP_CHECK(hipMemcpyAsync(cb.h_status.data(), cb.status.p, n, hipMemcpyDeviceToHost, r.stream));
 }
@@ -1965,7 +1975,8 @@ void for_each_replica(awry_index* ix, uint64_t n, F&& fn) {
   for (auto& e : errs) if (e) std::rethrow_exception(e);
 }
 
-// result arrays handed to the caller (released with free()); large ones 2 MB-aligned and advised for huge pages, see MBuf
+// small result arrays of the single-query entry points (awry_locate): plain heap memory, which awry_free_buffer tells
+// apart from the pinned pool blocks of the batch paths (release_result); large ones 2 MB-aligned and advised for huge pages
 template <class T>
 T* malloc_array(size_t n) {
   const size_t bytes = std::max<size_t>(1, n) * sizeof(T);
@@ -2295,7 +2306,7 @@ void awry_free_buffer(void* p) { release_result(p); }
 namespace {
 // one query through the replica's pinned mailbox; want_rows: the range must be a row interval (no text shortcut)
 // (the caller holds r.mailbox_mu)
-void single_query(Replica& r, const uint8_t* q, uint64_t len, bool want_rows, uint64_t& count, uint64_t& start, uint64_t& end) {
+void single_query(Replica& r, const uint8_t* q, uint64_t len, bool want_rows, uint64_t& count, uint64_t& start, uint64_t& end, int ref_kmer_len = -1) {
   Replica::Mailbox& m = r.mailbox;
   if (!m.q) {
     HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&m.q), Replica::Mailbox::QCAP + 16, hipHostMallocDefault));
@@ -2307,7 +2318,7 @@ void single_query(Replica& r, const uint8_t* q, uint64_t len, bool want_rows, ui
   m.words[0] = 0;
   m.words[1] = len;
   uint8_t* status = reinterpret_cast<uint8_t*>(m.words + 5);
-  launch_count_ascii(r, m.q, m.words, 1, m.words + 2, m.words + 3, status, r.stream, !want_rows);
+  launch_count_ascii(r, m.q, m.words, 1, m.words + 2, m.words + 3, status, r.stream, !want_rows, 0, want_rows ? ref_kmer_len : -1);
   HIP_CHECK(hipStreamSynchronize(r.stream));
   if (*status != Q_OK) {
     ChunkBuffers cb;
@@ -2339,12 +2350,12 @@ int awry_search_range(awry_index_t* idx, const uint8_t* q, uint64_t len, awry_ra
     if (len <= Replica::Mailbox::QCAP) {
       uint64_t c = 0;
       std::lock_guard<std::mutex> lock(r.mailbox_mu);
-      single_query(r, q, len, true, c, out->start_ptr, out->end_ptr);
+      single_query(r, q, len, true, c, out->start_ptr, out->end_ptr, (int)idx->host.kmer_len);
       return;
     }
     ChunkBuffers cb;
     const uint64_t off[2] = {0, len};
-    run_count_chunk(r, cb, q, off, Shard{0, 1}, true, false);  // the caller wants rows
+    run_count_chunk(r, cb, q, off, Shard{0, 1}, true, false, (int)idx->host.kmer_len);  // the caller wants rows: the reference's schedule
     uint64_t h[2];
     HIP_CHECK(hipMemcpyAsync(h, cb.ranges.p, 16, hipMemcpyDeviceToHost, r.stream));
     HIP_CHECK(hipStreamSynchronize(r.stream));

@@ -293,7 +293,12 @@ __global__ __launch_bounds__(256) void count_scalar_kernel(DevIndex ix, const ui
     if (st == Q_OK) {
       uint64_t i = e - 1;
       bool seeded = false;
-      if (A == AMINO && ix.seed && e - b >= (uint64_t)ix.seed_k) {  // last k residues all standard -> one table probe
+      // reference schedule (awry_search_range): no table, and kmer_len - 1 steps taken whether or not the range is empty
+      // (src/kmer_lookup_table.rs:90-110), so that the rows of an ABSENT query are the reference's too
+      const bool ref_mode = (allow_verify & 2) != 0;
+      uint64_t uncond = ref_mode && e - b >= (uint64_t)(allow_verify >> 8) && (allow_verify >> 8) > 0 ? (uint64_t)(allow_verify >> 8) - 1 : 0;
+      if (ref_mode) allow_verify = 0;
+      if (!ref_mode && A == AMINO && ix.seed && e - b >= (uint64_t)ix.seed_k) {  // last k residues all standard -> one table probe
         const int k = ix.seed_k;
         uint64_t sidx = 0;
         bool std20 = true;
@@ -329,7 +334,7 @@ __global__ __launch_bounds__(256) void count_scalar_kernel(DevIndex ix, const ui
           }
         }
       }
-      if (A == NUCLEOTIDE && ix.seed && e - b >= (uint64_t)ix.seed_k) {  // last k symbols all in ACGT -> one table probe
+      if (!ref_mode && A == NUCLEOTIDE && ix.seed && e - b >= (uint64_t)ix.seed_k) {  // last k symbols all in ACGT -> one table probe
         const int k = ix.seed_k;
         uint64_t sidx = 0;
         bool acgt = true;
@@ -373,7 +378,8 @@ __global__ __launch_bounds__(256) void count_scalar_kernel(DevIndex ix, const ui
         ep = ix.prefix_sums[idx + 1] - 1;
       }
       const bool can_verify = allow_verify && ix.text8 && ix.dense_sa && ix.dense_ratio == 1;
-      while (i > b && sp <= ep) {        // emptiness is sticky, so stopping early never changes the count
+      while (i > b && (sp <= ep || uncond > 0)) {  // emptiness is sticky, so stopping early never changes the count
+        if (uncond > 0) uncond--;
         const uint64_t rem = i - b, cnt = ep - sp + 1;
         // (second pass of the amino k-mer schedule: what counts there is the length of the chain of dependent loads, and
         //  SA + text is two of them where every LF step is one more)
@@ -552,12 +558,21 @@ __global__ __launch_bounds__(256) void count_aa_kmer_probe_kernel(DevIndex ix, c
           const uint64_t b = off[qv[h]], len = off[qv[h] + 1] - b;
           odd[h] = len < (uint64_t)(k > 1 ? k : 1) || len > (uint64_t)(LONG ? AA_KMER_LONG_MAX : AA_KMER_MAX);
           Lq[h] = odd[h] ? AA_KMER_MAX : (len > (uint64_t)AA_KMER_MAX ? AA_KMER_MAX : (int)len);
-          if (!odd[h]) {  // (reads up to 7 bytes past the query: the buffer's documented slack covers the last one)
+          if (!odd[h]) {  // never reads a byte past the query's last one (a caller's buffer may end right there)
             if (LONG) { far[h] = (int)len - Lq[h]; qp[h] = ascii + b; }
-            const uint8_t* p = ascii + b + (LONG ? (uint64_t)far[h] : 0ull);
-            c0[h] = ld8(p);
-            if (Lq[h] > 8) c1[h] = ld8(p + 8);
-            if (Lq[h] > 16) c2[h] = ld8(p + 16);
+            const uint64_t first = b + (LONG ? (uint64_t)far[h] : 0ull);
+            const uint8_t* p = ascii + first;
+            const int Lt = Lq[h];
+            if (Lt >= 8) {  // the last word is anchored at the query's end, as in the equal-length branch
+              c0[h] = ld8(p);
+              const uint64_t last = ld8(p + Lt - 8);
+              if (Lt >= 16) { c1[h] = ld8(p + 8); if (Lt > 16) c2[h] = last >> (8 * (24 - Lt)); }
+              else if (Lt > 8) c1[h] = last >> (8 * (16 - Lt));
+            } else if (first + (uint64_t)Lt >= 8) {  // shorter than a word: the word that ENDS with the query
+              c0[h] = ld8(p + Lt - 8) >> (8 * (8 - Lt));
+            } else {  // within the buffer's first seven bytes
+              for (int t = 0; t < Lt; t++) c0[h] |= (uint64_t)p[t] << (8 * t);
+            }
           }
         } else {
           const int Lt = Lq[h];

@@ -79,7 +79,12 @@ void awry_free(awry_index_t *idx);
  * the locate / verify accelerators (7 B per text symbol) when they fit in half of it -- ~160 GB for a GRCh38-scale
  * index; AWRY_HBM_BUDGET_GB caps the figure they plan with, AWRY_SEED_K / AWRY_VERIFY=0 pin the choices.  Later, the first
  * batch of >= 4096 nucleotide k-mers of a length L below the seed table's k adds a complete 4^L table for that length
- * (8 B x 4^L: 134 MB for L = 12, 34 GB for L = 16) when it fits half of the free HBM; AWRY_SEED_RUNGS=0 turns that off. */
+ * (8 B x 4^L: 134 MB for L = 12, 34 GB for L = 16) when it fits half of the free HBM and all such tables of the replica stay
+ * below AWRY_SEED_RUNG_GB (default 48); that first call builds the table (1.3 s for L = 16) while it holds the replica's
+ * lane; AWRY_SEED_RUNGS=0 turns the feature off.
+ * If building a replica fails (out of HBM on one of several GPUs, say) the index is left with NO replicas -- the old ones are
+ * released first, because the policies size their tables from the HBM that is free -- and every query returns
+ * AWRY_ERR_NO_DEVICE until a later awry_set_devices succeeds; do not call it while another thread is inside a batch call. */
 int awry_set_devices(awry_index_t *idx, const int *device_ids, int n_devices);
 /* device-side seed-table length (performance knob only; results do not depend on it).  0 disables,
  * -1 picks the default.  Takes effect immediately on all replicas. */
@@ -121,7 +126,7 @@ int awry_num_devices(const awry_index_t *idx);
 int awry_count_batch(awry_index_t *idx, const uint8_t *qbytes, const uint64_t *qoff, uint64_t n, uint64_t *counts_out);
 /* no counterpart in the reference: the same for callers that already hold their k-mers packed (k-mer counters do) --
  * n k-mers of L <= 32 letters, letter j (0 = leftmost) of k-mer i in bits [2j, 2j + 2) of words[i], A0 C1 G2 T3;
- * nucleotide indexes with bwt_len < 2^32.  16 B per query cross PCIe instead of L + 8. */
+ * nucleotide indexes of any size (2^32 rows or more: the wide-row kernels).  16 B per query cross PCIe instead of L + 8. */
 int awry_count_packed_kmers(awry_index_t *idx, const uint64_t *words, uint64_t n, int L, uint64_t *counts_out);
 /* FmIndex::parallel_locate, src/fm_index.rs:479-487.  CSR output, library-allocated (awry_free_buffer):
  * hits of query i are [hit_off[i], hit_off[i+1]) in ascending BWT-row order (src/fm_index.rs:521);
@@ -137,7 +142,11 @@ void awry_free_buffer(void *p);
 
 /* ---- scalar conveniences (each launches on replica 0) ---------------------------------------------- */
 int awry_count(awry_index_t *idx, const uint8_t *q, uint64_t len, uint64_t *count);          /* count_string :499  */
-int awry_search_range(awry_index_t *idx, const uint8_t *q, uint64_t len, awry_range_t *out); /* :402-438          */
+/* get_search_range_for_string (pub(crate) in the reference, :402-438): the row interval of q.  It follows the reference's own
+ * step schedule -- no device seed table; for len >= lookup_table_kmer_len the first kmer_len - 1 steps are taken whether or
+ * not the range is already empty (src/kmer_lookup_table.rs:90-110) -- so an ABSENT query returns the same (start_ptr, end_ptr)
+ * as the reference (start_ptr = end_ptr + 1, not a canonical {1, 0}); pinned against the oracle in tests/test_gpu_parity.py */
+int awry_search_range(awry_index_t *idx, const uint8_t *q, uint64_t len, awry_range_t *out);
 int awry_locate(awry_index_t *idx, const uint8_t *q, uint64_t len, awry_pos_t **hits_out,
                 uint64_t **global_pos_out, uint64_t *n_hits);                                /* locate_string :516 */
 int awry_initial_range(const awry_index_t *idx, uint8_t symbol_ascii, awry_range_t *out);    /* :383-385          */

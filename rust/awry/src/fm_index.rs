@@ -410,6 +410,9 @@ impl FmIndex {
     /// Passes `hits_out = NULL`: 8 bytes per hit cross PCIe instead of 24.
     pub fn locate_batch_positions(&self, bytes: &[u8], offsets: &[u64]) -> Result<(Vec<u64>, Vec<u64>), AwryError> {
         assert!(!offsets.is_empty());
+        // the C side reads bytes[offsets[i]..offsets[i + 1]]: a safe fn must not let bad offsets reach it
+        assert!(offsets.windows(2).all(|w| w[0] <= w[1]), "query offsets must be non-decreasing");
+        assert!(*offsets.last().unwrap() as usize <= bytes.len(), "query offsets run past the byte buffer");
         let n = offsets.len() - 1;
         let mut hit_off: *mut u64 = std::ptr::null_mut();
         let mut gpos: *mut u64 = std::ptr::null_mut();

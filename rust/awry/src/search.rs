@@ -13,37 +13,33 @@ pub struct SearchRange {
 }
 
 impl SearchRange {
-    /// The range of all suffixes that start with `symbol`: `[C[s], C[s + 1] - 1]`.
+    /// The range of all suffixes that start with `symbol`: rows `C[s] ..= C[s + 1] - 1`, where `C` are the index's
+    /// prefix sums (one sentinel row precedes every letter, so `C[s + 1] >= 1` and the subtraction cannot wrap).
     pub fn new(fm_index: &FmIndex, symbol: Symbol) -> Self {
-        SearchRange {
-            start_ptr: fm_index.prefix_sums()[symbol.index() as usize] as SearchPtr,
-            end_ptr: fm_index.prefix_sums()[(symbol.index() + 1) as usize] - 1 as SearchPtr,
-        }
+        let c = fm_index.prefix_sums();
+        let s = usize::from(symbol.index());
+        let (first, next): (SearchPtr, SearchPtr) = (c[s], c[s + 1]);
+        Self { start_ptr: first, end_ptr: next.wrapping_sub(1) }
     }
-    /// An invalid range (no elements).
+    /// The canonical empty range `{1, 0}`.
     pub fn zero() -> Self {
-        SearchRange { start_ptr: 1, end_ptr: 0 }
+        Self { start_ptr: 1, end_ptr: 0 }
     }
-    /// True if the range represents no element.
+    /// A range is empty exactly when its end lies before its start.
     #[inline]
     pub fn is_empty(&self) -> bool {
-        self.start_ptr > self.end_ptr
+        self.end_ptr < self.start_ptr
     }
-    /// Number of elements the range represents.
+    /// Rows in the range (`0` for an empty one; never wraps).
     #[inline]
     pub fn len(&self) -> SearchPtr {
-        match self.is_empty() {
-            true => 0,
-            false => self.end_ptr - self.start_ptr + 1,
-        }
+        self.end_ptr.checked_sub(self.start_ptr).map_or(0, |d| d + 1)
     }
-    /// Iterator over the BWT rows of the range.
+    /// The rows of the range in ascending order; nothing for an empty range.
     #[inline]
     pub fn range_iter(&self) -> core::ops::Range<SearchPtr> {
-        match self.is_empty() {
-            true => 0..0,
-            false => self.start_ptr..(self.end_ptr + 1),
-        }
+        let n = self.len();
+        if n == 0 { 0..0 } else { self.start_ptr..self.start_ptr + n }
     }
 }
 

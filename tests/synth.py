@@ -109,3 +109,135 @@ def write_fasta(path, text, starts, headers, width=80):
             rec = bytes(text[s:e])
             for i in range(0, len(rec), width):
                 f.write(rec[i:i + width] + b"\n")
+
+
+# ------------------------------------------------------------------------------------------------ repeat-rich genome
+# A GRCh38-shaped text: the composition a real mammalian genome confronts an FM-index with and an i.i.d. text does not --
+# interspersed repeat families (300 bp .. 6 kb units, 10^3 .. 10^6 copies at full scale, 2 .. 15 % divergence from the
+# family consensus), satellite and simple tandem arrays, segmental duplications, assembly gaps (runs of N) and 25 records.
+# Fractions are of the text length, so the same recipe scales from test sizes (a few Mbp) to 3.1 Gbp.
+#   (name, unit length, fraction of the text, per-base divergence from the consensus, truncated 5' ends)
+REPEAT_FAMILIES = (
+    ("alu_old", 300, 0.100, 0.12, False),     # 1.0 M copies at 3.1 Gbp
+    ("alu_young", 300, 0.019, 0.04, False),   # 0.2 M
+    ("l1", 6000, 0.180, 0.10, True),          # 0.18 M copies of 300 .. 6000 bp (the 3' end of the unit)
+    ("ltr", 1000, 0.085, 0.15, False),        # 0.26 M
+    ("dna", 2000, 0.032, 0.06, False),        # 50 k
+    ("l1_young", 6000, 0.010, 0.02, False),   # 5 k full-length copies at 2 %
+    ("mir", 260, 0.035, 0.15, False),         # 0.4 M
+)
+SATELLITE_FRACTION, SATELLITE_ARRAYS, SATELLITE_UNIT = 0.020, 30, 171   # per-copy divergence 2 %, array-specific unit variants 5 %
+SIMPLE_TANDEM = ((5, 0.003), (37, 0.0005))                              # exact tandem arrays: (unit, fraction)
+SEGDUP_FRACTION, SEGDUP_MIN, SEGDUP_MAX = 0.048, 10_000, 200_000        # copies of existing stretches at 1 .. 5 % divergence
+GAP_FRACTION_BIG, GAP_BIG, GAP_FRACTION_SMALL, GAP_SMALL = 0.043, 24, 0.007, 500
+
+
+def repeat_rich_text(n, seed=11, n_records=25, device="cpu", scale=1.0):
+    """-> (text uint8[n+1] numpy incl. '$', seq_starts, headers, info dict).  Generated with torch on `device` (a 3.1 Gbp
+    text takes ~2 s on the GPU, minutes in numpy).  The text depends on (n, seed, device type): CPU and GPU generators draw
+    different streams.  `scale` multiplies every repeat fraction (1.0: ~43 % of the text in repeats, counted after overlaps)."""
+    import torch
+    dev = torch.device(device)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(seed)
+    lut = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)
+
+    def rnd_letters(shape):
+        return torch.randint(0, 4, shape, dtype=torch.uint8, device=dev, generator=gen)
+
+    code = rnd_letters((n,))                      # 0..3, mapped to ACGT at the end; 4 = N
+    covered = torch.zeros(n, dtype=torch.bool, device=dev)
+    info = {"families": {}}
+
+    def mutate(x, div):
+        m = torch.rand(x.shape, device=dev, generator=gen) < div
+        return torch.where(m, rnd_letters(x.shape), x)   # a quarter of the "mutations" redraw the same letter
+
+    def spaced_starts(copies, span, hi):
+        """`copies` sorted start positions in [0, hi) at least `span` apart (copies of one family never overlap, so the
+        result does not depend on the order in which a scatter writes them)"""
+        if copies <= 0 or hi <= span * copies:
+            copies = max(0, min(copies, int(hi // (2 * span))))
+        if copies == 0:
+            return torch.zeros(0, dtype=torch.int64, device=dev)
+        p = torch.sort(torch.randint(0, int(hi - span * copies), (copies,), device=dev, generator=gen)).values
+        return p + torch.arange(copies, device=dev) * span
+
+    chunk_elems = 48_000_000
+    for name, unit, frac, div, trunc in REPEAT_FAMILIES:
+        frac *= scale
+        mean_len = (unit + 300) / 2 if trunc else unit
+        copies = int(frac * n / mean_len)
+        cons = rnd_letters((unit,))
+        starts = spaced_starts(copies, unit, n - unit - 1)
+        per = max(1, chunk_elems // unit)
+        ar = torch.arange(unit, device=dev)
+        for a in range(0, len(starts), per):
+            st = starts[a:a + per]
+            vals = mutate(cons[None, :].expand(len(st), unit), div)
+            idx = st[:, None] + ar[None, :]
+            if trunc:  # the copy keeps the last `len` letters of the unit
+                ln = torch.randint(min(300, unit), unit + 1, (len(st),), device=dev, generator=gen)
+                keep = ar[None, :] >= (unit - ln)[:, None]
+                idx, vals = idx[keep], vals[keep]
+            code[idx.reshape(-1)] = vals.reshape(-1)
+            covered[idx.reshape(-1)] = True
+            del vals, idx
+        info["families"][name] = {"unit": unit, "copies": int(len(starts)), "divergence": div}
+    # satellite arrays: tandem copies of an array-specific variant of one of three base units
+    bases = [rnd_letters((SATELLITE_UNIT,)) for _ in range(3)]
+    per_array = int(SATELLITE_FRACTION * scale * n / SATELLITE_ARRAYS / SATELLITE_UNIT)
+    if per_array >= 2:
+        a_starts = spaced_starts(SATELLITE_ARRAYS, per_array * SATELLITE_UNIT, n - per_array * SATELLITE_UNIT - 1)
+        for j, s in enumerate(a_starts.tolist()):
+            unit_a = mutate(bases[j % 3], 0.05)
+            arr = mutate(unit_a.repeat(per_array), 0.02)
+            code[s:s + arr.numel()] = arr
+            covered[s:s + arr.numel()] = True
+        info["satellite"] = {"arrays": int(len(a_starts)), "copies_per_array": per_array, "unit": SATELLITE_UNIT}
+    for unit, frac in SIMPLE_TANDEM:
+        reps = int(frac * scale * n / unit)
+        if reps >= 2:
+            s = int(torch.randint(0, n - reps * unit - 1, (1,), device=dev, generator=gen).item())
+            code[s:s + reps * unit] = rnd_letters((unit,)).repeat(reps)
+            covered[s:s + reps * unit] = True
+    # segmental duplications: stretches of the text as it now stands (repeats included), copied elsewhere at 1 .. 5 %
+    seg_hi = max(SEGDUP_MIN // 10, min(SEGDUP_MAX, n // 100))
+    seg_lo = max(100, min(SEGDUP_MIN, seg_hi // 2))
+    ndup = int(SEGDUP_FRACTION * scale * n / ((seg_lo + seg_hi) / 2))
+    if ndup:
+        lens = torch.randint(seg_lo, seg_hi + 1, (ndup,), device=dev, generator=gen).tolist()
+        srcs = torch.randint(0, n - seg_hi - 1, (ndup,), device=dev, generator=gen).tolist()
+        dsts = spaced_starts(ndup, seg_hi, n - seg_hi - 1).tolist()
+        divs = (0.01 + 0.04 * torch.rand(ndup, device=dev, generator=gen)).tolist()
+        for ln, s, d, dv in zip(lens, srcs, dsts, divs):
+            code[d:d + ln] = mutate(code[s:s + ln].clone(), dv)
+            covered[d:d + ln] = True
+        info["segdups"] = {"count": ndup, "len": [seg_lo, seg_hi]}
+    info["repeat_fraction"] = float(covered.float().mean().item())
+    del covered
+    # assembly gaps: a few megabase runs and many small ones
+    big = int(GAP_FRACTION_BIG * n / GAP_BIG)
+    if big >= 1:
+        for s in spaced_starts(GAP_BIG, big, n - big - 1).tolist():
+            code[s:s + big] = 4
+    nsmall = min(GAP_SMALL, n // 20_000)
+    if nsmall:
+        small = max(1, int(GAP_FRACTION_SMALL * n / nsmall))
+        for s in spaced_starts(nsmall, small, n - small - 1).tolist():
+            code[s:s + small] = 4
+    starts = [0]
+    if n_records > 1:
+        cuts = torch.sort(torch.randperm(n - 2, device=dev, generator=gen)[:n_records - 1] + 1).values.tolist() if n < (1 << 24) else \
+            sorted(set(torch.randint(1, n - 1, (n_records - 1,), device=dev, generator=gen).tolist()))
+        for c in cuts:
+            code[c] = 4  # the delimiter byte between records
+            starts.append(int(c) + 1)
+    info["n_fraction"] = float((code == 4).float().mean().item())
+    lut5 = torch.tensor(list(b"ACGTN"), dtype=torch.uint8, device=dev)
+    body = lut5[code.long()] if n < (1 << 28) else torch.cat([lut5[code[a:a + (1 << 28)].long()] for a in range(0, n, 1 << 28)])
+    del code
+    text = np.empty(n + 1, dtype=np.uint8)
+    text[:n] = body.cpu().numpy()
+    text[n] = ord("$")
+    return text, starts, ["seq%d" % i for i in range(len(starts))], info

@@ -81,10 +81,14 @@ def test_count_and_locate_match_oracle(oracle, alphabet, n, recs, nfrac, ratio):
     assert np.array_equal(off, ooff)
     assert np.array_equal(gpos, ogpos)  # same order too: ascending BWT row, src/fm_index.rs:521
     assert np.array_equal(pos, opos)
-    for q in qs[:40]:
-        if oi.count_string(q):
-            r = ix.search_range(q)
-            assert (r.start_ptr, r.end_ptr) == oi.search_range(q)
+    # get_search_range_for_string: the reference's own rows, for ABSENT queries too -- awry_search_range runs the reference's
+    # step schedule (lookup_table_kmer_len - 1 steps taken whether or not the range is empty, src/kmer_lookup_table.rs:90-110)
+    absent = 0
+    for q in qs[:120]:
+        r = ix.search_range(q)
+        assert (r.start_ptr, r.end_ptr) == oi.search_range(q), q
+        absent += 0 if oi.count_string(q) else 1
+    assert absent >= 10
 
 
 @pytest.mark.parametrize("n,recs,nfrac", [(200000, 1, 0.0), (400000, 3, 0.07)])
@@ -125,11 +129,15 @@ def test_scalar_entry_points_match_oracle(oracle):
     ao = oracle.OracleIndex.from_text(aa_text, 1, 8, 0, st, hd)
     for row in rng.integers(0, len(aa_text), 60).tolist():
         assert ax.backstep(int(row)) == ao.backstep(int(row))
-    for i, ch in enumerate("ACDEFGHIKLMNPQRSTVWXY", start=1):
+    letters = "ACDEFGHIKLMNPQRSTVWXY"  # symbol indices 1..21 (src/alphabet.rs:280-303)
+    for i, ch in enumerate(letters, start=1):
         r0 = ax.initial_search_range(ch)
         assert (r0.start_ptr, r0.end_ptr) == ao.initial_search_range(i)
-        r1 = ax.update_range_with_symbol(r0, "L")
-        assert (r1.start_ptr, r1.end_ptr) == ao.update_range_with_symbol(r0.start_ptr, r0.end_ptr, 10)
+        for j, ch2 in enumerate(letters, start=1):  # update_range_with_symbol over all 21 x 21 symbol pairs, and one step further
+            r1 = ax.update_range_with_symbol(r0, ch2)
+            assert (r1.start_ptr, r1.end_ptr) == ao.update_range_with_symbol(r0.start_ptr, r0.end_ptr, j), (ch, ch2)
+            r2 = ax.update_range_with_symbol(r1, letters[(i + j) % 21])  # (also from empty ranges: emptiness is sticky, src/fm_index.rs:559-582)
+            assert (r2.start_ptr, r2.end_ptr) == ao.update_range_with_symbol(r1.start_ptr, r1.end_ptr, (i + j) % 21 + 1), (ch, ch2)
 
 
 def test_undefined_queries_are_rejected():
@@ -1571,3 +1579,24 @@ def test_wide_row_kernels(oracle):
     assert all(np.array_equal(x, y) for x, y in zip(got, want))
     with pytest.raises(AwryError):
         ix.set_verify(2)  # the verify accelerators are 32-bit structures
+
+
+def test_ecoli_scale_21mers_against_the_oracle(oracle):
+    """BASELINE configs[0]'s shape on the HIP path: an E. coli K-12-sized text (4.6 Mbp, one record), 10 k random and 10 k
+    present 21-mers, counts through the host boundary and the packed kernels, locations of the present ones -- all against
+    the oracle (which is what configs[0] itself runs, on the CPU)."""
+    text, st, hd = synth.make_text(4_641_652, 0, 0xA5A50000 + 1, 1, 0.0)
+    ix = gpu_index(text, 0, 8, 0, st, hd)
+    oi = oracle.OracleIndex.from_text(text, 0, 8, 0, st, hd)
+    q2d = np.concatenate([synth.random_queries(10_000, 21, 0, 0xA5A50001), synth.sampled_queries(text, 10_000, 21, 5)])
+    qb, qo = synth.fixed_to_csr(q2d)
+    want, _ = oi.parallel_count(qb, qo, 4)
+    assert np.array_equal(ix.parallel_count_csr(qb, qo), want)
+    assert np.array_equal(ix.count_kmers_nt2(q2d, True), want)
+    assert np.array_equal(ix.count_kmers_nt2(q2d, False), want)
+    assert (want[10_000:] >= 1).all() and want[:10_000].sum() <= 10  # a random 21-mer in 4.6 Mbp: 1e-6 each
+    off, gpos, pos = ix.parallel_locate_csr(qb, qo)
+    ooff, ogpos, opos, _ = oi.parallel_locate(qb, qo, 4)
+    assert np.array_equal(off, ooff) and np.array_equal(gpos, ogpos) and np.array_equal(pos, opos)
+    for q in (q2d[0], q2d[10_000], q2d[19_999]):
+        assert ix.count_string(bytes(q)) == oi.count_string(bytes(q))

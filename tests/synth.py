@@ -126,8 +126,9 @@ REPEAT_FAMILIES = (
     ("l1_young", 6000, 0.010, 0.02, False),   # 5 k full-length copies at 2 %
     ("mir", 260, 0.035, 0.15, False),         # 0.4 M
 )
-SATELLITE_FRACTION, SATELLITE_ARRAYS, SATELLITE_UNIT = 0.020, 30, 171   # per-copy divergence 2 %, array-specific unit variants 5 %
-SIMPLE_TANDEM = ((5, 0.003), (37, 0.0005))                              # exact tandem arrays: (unit, fraction)
+SATELLITE_FRACTION, SATELLITE_ARRAYS, SATELLITE_UNIT = 0.020, 120, 171  # per-copy divergence 2 %, array-specific unit variants 5 %
+# exact tandem arrays, each with a unit of its own: (unit lengths, array lengths, fraction) -- microsatellites and minisatellites
+SIMPLE_TANDEM = (((2, 6), (20, 200), 0.003), ((20, 60), (2000, 20000), 0.0005))
 SEGDUP_FRACTION, SEGDUP_MIN, SEGDUP_MAX = 0.048, 10_000, 200_000        # copies of existing stretches at 1 .. 5 % divergence
 GAP_FRACTION_BIG, GAP_BIG, GAP_FRACTION_SMALL, GAP_SMALL = 0.043, 24, 0.007, 500
 
@@ -195,12 +196,24 @@ def repeat_rich_text(n, seed=11, n_records=25, device="cpu", scale=1.0):
             code[s:s + arr.numel()] = arr
             covered[s:s + arr.numel()] = True
         info["satellite"] = {"arrays": int(len(a_starts)), "copies_per_array": per_array, "unit": SATELLITE_UNIT}
-    for unit, frac in SIMPLE_TANDEM:
-        reps = int(frac * scale * n / unit)
-        if reps >= 2:
-            s = int(torch.randint(0, n - reps * unit - 1, (1,), device=dev, generator=gen).item())
-            code[s:s + reps * unit] = rnd_letters((unit,)).repeat(reps)
-            covered[s:s + reps * unit] = True
+    for (u_lo, u_hi), (a_lo, a_hi), frac in SIMPLE_TANDEM:
+        a_hi = max(a_lo // 10 + 1, min(a_hi, n // 1000))
+        a_lo = min(a_lo, a_hi)
+        narr = int(frac * scale * n / ((a_lo + a_hi) / 2))
+        a_starts = spaced_starts(narr, a_hi, n - a_hi - 1) if narr >= 1 else []
+        if len(a_starts) == 0:
+            continue
+        na = len(a_starts)
+        units = torch.randint(u_lo, u_hi + 1, (na,), device=dev, generator=gen)
+        lens = torch.randint(a_lo, a_hi + 1, (na,), device=dev, generator=gen)
+        pool = rnd_letters((na * u_hi,))                     # array j repeats pool[j * u_hi : j * u_hi + units[j]]
+        arr_id = torch.repeat_interleave(torch.arange(na, device=dev), lens)
+        within = torch.arange(int(lens.sum().item()), device=dev) - torch.repeat_interleave(torch.cumsum(lens, 0) - lens, lens)
+        idx = a_starts[arr_id] + within
+        code[idx] = pool[arr_id * u_hi + within % units[arr_id]]
+        covered[idx] = True
+        info.setdefault("tandem_arrays", []).append({"arrays": na, "unit": [u_lo, u_hi], "length": [a_lo, a_hi]})
+        del arr_id, within, idx
     # segmental duplications: stretches of the text as it now stands (repeats included), copied elsewhere at 1 .. 5 %
     seg_hi = max(SEGDUP_MIN // 10, min(SEGDUP_MAX, n // 100))
     seg_lo = max(100, min(SEGDUP_MIN, seg_hi // 2))

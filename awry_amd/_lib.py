@@ -126,6 +126,10 @@ def load_library():
     sig("awry_set_verify", i32, vp, i32)
     sig("awry_verify_enabled", i32, vp)
     sig("awry_set_verify_kmers", i32, vp, i32)
+    sig("awry_set_lcx", i32, vp, i32)
+    sig("awry_lcx_enabled", i32, vp)
+    sig("awry_debug_lcx", i32, vp, i32, vpp, vpp)
+    sig("awry_dev_stream_copy", i32, vp, i32, vp, vp, u64, vp)
     sig("awry_dev_malloc", i32, vp, i32, u64, vpp)
     sig("awry_dev_free", i32, vp, i32, vp)
     sig("awry_dev_memcpy_h2d", i32, vp, i32, vp, vp, u64)

@@ -3,6 +3,9 @@
 #include "../../include/awry_hip.h"
 
 #include <hip/hip_runtime.h>
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_select.hpp>
+#include <rocprim/iterator/counting_iterator.hpp>
 
 #include <sys/mman.h>
 
@@ -195,6 +198,7 @@ struct Replica {
   DevBuf<uint8_t> text8;                      // the text as symbol indices, for the generic kernel's verify (any alphabet)
   DevBuf<uint32_t> dense_sa;                  // SA[j * dense_ratio] as u32 (device-only accelerator for locate)
   DevBuf<uint32_t> sa_nblock;                 // SA of the rows whose suffix starts with N (kept while locate has to walk)
+  DevBuf<uint64_t> lcx_key, lcx_rowpos, lcx_inner;  // left-context index (layout.h, DevIndex::lcx_key); kept with position seeds
   uint32_t dense_ratio = 0;                   // 0 = use the file's bit-packed samples
   bool verify_kmers = false;                  // also use seed-and-verify in the k-mer (L <= 32) kernel
   // survivor lists of the two-phase count schedule, one per stream (launches on one stream are ordered, so reuse is safe)
@@ -227,6 +231,7 @@ struct Replica {
       blocks.reset(); sa_words.reset(); seq_starts.reset(); seed.reset(); seed64.reset(); rungs.clear(); dense_sa.reset(); text4.reset();
       scratch.clear();
       sa_nblock.reset(); text8.reset();
+      lcx_key.reset(); lcx_rowpos.reset(); lcx_inner.reset();
     }
   }
 };
@@ -240,6 +245,7 @@ struct awry_index {
   int dense_ratio_request = 0;  // 0 = locate walks to the file's SA samples
   int verify_request = -2;      // -2: policy; -1: seed-and-verify off; >= 0: LF steps before switching to text comparison
   bool verify_kmers_request = false;
+  int lcx_request = -1;         // -1: policy (on when it fits); 0: no left-context index; 1: as -1
 };
 
 namespace {
@@ -407,7 +413,14 @@ const SeedEntry* seed_rung(Replica& r, int L) {
 }
 
 // level-by-level seed table on the replica's device (see seed_extend_kernel)
+void drop_lcx(Replica& r) {
+  r.lcx_key.reset(); r.lcx_rowpos.reset(); r.lcx_inner.reset();
+  r.dev.lcx_key = r.dev.lcx_rowpos = r.dev.lcx_inner = nullptr;
+  for (auto& o : r.dev.lcx_off) o = 0;
+}
+
 void build_seed(awry_index* ix, Replica& r, int k) {
+  drop_lcx(r);  // its flags live in the table's entries
   r.seed.reset();
   r.seed_k = 0;
   r.dev.seed = nullptr;
@@ -453,7 +466,120 @@ void build_seed(awry_index* ix, Replica& r, int k) {
 
 void build_dense_sa(awry_index* ix, Replica& r, int ratio);
 void build_verify(awry_index* ix, Replica& r, int after_steps);
+void sync_seed_mode(awry_index* ix, Replica& r);
 void refresh_nblock(awry_index* ix, Replica& r);
+
+bool lcx_wanted(const awry_index* ix) {
+  static const bool off = getenv("AWRY_LCX") && !strcmp(getenv("AWRY_LCX"), "0");
+  return !off && ix->lcx_request != 0;
+}
+
+// The left-context index of a nucleotide replica (layout.h, lcx.hip.h): 16 B per row for the keys and the (position, row)
+// pairs, 0.6 B for the sampled levels.  Built from what is resident anyway -- the final seed table (its 2+ row entries name
+// the buckets), the ratio-1 dense SA, the 4-bit text -- in chunks of rows cut at bucket boundaries: per chunk two stable radix
+// sorts (context key, then bucket) order the covered rows, which then go back to their buckets' own row slots.
+// Skipped (returns false) when the HBM that is free does not hold it and its build scratch with room to spare.
+bool build_lcx(awry_index* ix, Replica& r) {
+  drop_lcx(r);
+  const HostIndex& h = ix->host;
+  if (r.wide || h.alphabet != NUCLEOTIDE || !r.seed.p || r.seed_k < 8 || !r.dev.text4 || !r.dense_sa.p || r.dense_ratio != 1) return false;
+  const uint64_t N = h.bwt_len, nfinal = 1ull << (2 * r.seed_k);
+  uint64_t lev_n[8] = {0}, lev_off[8] = {0}, inner_total = 16;
+  for (int t = 1; t <= 7; t++) {
+    lev_n[t] = ((((N - 1) >> (4 * t)) + 1 + 15) / 16) * 16 + 16;  // whole nodes, one to spare
+    lev_off[t] = inner_total;
+    inner_total += lev_n[t];
+  }
+  const double resident = 16.0 * (double)(N + 32) + 8.0 * (double)inner_total;
+  size_t free_b = 0;
+  if (!hbm_budget(&free_b)) return false;
+  constexpr double PER_ROW = 96.0;  // build scratch per row of a chunk (row info 17 B, covered rows 4 B, two double-buffered pair sorts 48 B, rocPRIM's own)
+  if (resident + PER_ROW * (double)(1u << 24) > 0.75 * (double)free_b) return false;
+  const uint64_t chunk = (uint64_t)std::max(1.0 * (1u << 24), std::min(1.0 * (1u << 28), (0.75 * (double)free_b - resident) / PER_ROW));
+  const uint32_t max_bucket = (uint32_t)std::min<uint64_t>(1u << 24, chunk / 2);
+  static const bool verbose = getenv("AWRY_VERBOSE") != nullptr;
+  const auto t_begin = std::chrono::steady_clock::now();
+  DevBuf<uint64_t> key(N + 32), rowpos(N + 32), inner(inner_total);
+  hipStream_t s = r.stream;
+  HIP_CHECK(hipMemsetAsync(key.p, 0, (N + 32) * 8, s));
+  HIP_CHECK(hipMemsetAsync(rowpos.p, 0, (N + 32) * 8, s));
+  hipLaunchKernelGGL(lcx_flag_big_kernel, dim3(grid_for(r, nfinal, 256)), dim3(256), 0, s, r.seed.p, nfinal, max_bucket);
+  HIP_CHECK(hipGetLastError());
+  {
+    const uint64_t cap = std::min(chunk + max_bucket, N);
+    DevBuf<uint64_t> bkey(cap), ckey(cap), k1a(cap), k1b(cap), b1a(cap), b1b(cap);
+    DevBuf<uint8_t> valid(cap);
+    DevBuf<uint32_t> slot(cap + 1), p1a(cap), p1b(cap), q2a(cap), q2b(cap), small(4);
+    size_t tmp_bytes = 0, need = 0;
+    {  // rocPRIM scratch: the largest of the three calls at full capacity
+      rocprim::double_buffer<uint64_t> dk(k1a.p, k1b.p);
+      rocprim::double_buffer<uint32_t> dv(p1a.p, p1b.p);
+      HIP_CHECK(rocprim::radix_sort_pairs(nullptr, need, dk, dv, (size_t)cap, 0, 64, s));
+      tmp_bytes = need;
+      HIP_CHECK(rocprim::select(nullptr, need, rocprim::counting_iterator<uint32_t>(0), valid.p, slot.p, small.p, (size_t)cap, s));
+      tmp_bytes = std::max(tmp_bytes, need);
+    }
+    DevBuf<uint8_t> tmp(tmp_bytes + 256);
+    uint32_t h_small[4];
+    uint64_t r0 = 0, covered = 0, nchunks = 0;
+    while (r0 < N) {
+      uint64_t r1 = std::min(N, r0 + chunk);
+      if (r1 < N) {  // cut at the first row of the bucket that holds row r1
+        hipLaunchKernelGGL(lcx_bucket_start_kernel, dim3(1), dim3(64), 0, s, r.dev, (uint32_t)r1, max_bucket, small.p + 1);
+        HIP_CHECK(hipMemcpyAsync(h_small, small.p + 1, 4, hipMemcpyDeviceToHost, s));
+        HIP_CHECK(hipStreamSynchronize(s));
+        if (h_small[0] > r0 && h_small[0] <= r1) r1 = h_small[0];
+      }
+      const uint64_t n = r1 - r0;
+      const dim3 g(grid_for(r, n, 256)), b(256);
+      hipLaunchKernelGGL(lcx_rowinfo_kernel, g, b, 0, s, r.dev, (uint32_t)r0, (uint32_t)n, max_bucket, bkey.p, ckey.p, valid.p);
+      need = tmp_bytes;
+      HIP_CHECK(rocprim::select(tmp.p, need, rocprim::counting_iterator<uint32_t>(0), valid.p, slot.p, small.p, (size_t)n, s));
+      HIP_CHECK(hipMemcpyAsync(h_small, small.p, 4, hipMemcpyDeviceToHost, s));
+      HIP_CHECK(hipStreamSynchronize(s));
+      const uint64_t nv = h_small[0];
+      if (nv) {
+        const dim3 gv(grid_for(r, nv, 256));
+        hipLaunchKernelGGL(lcx_gather_u64_kernel, gv, b, 0, s, ckey.p, slot.p, nv, k1a.p);
+        hipLaunchKernelGGL(lcx_iota_kernel, gv, b, 0, s, p1a.p, nv);
+        rocprim::double_buffer<uint64_t> dk(k1a.p, k1b.p);
+        rocprim::double_buffer<uint32_t> dv(p1a.p, p1b.p);
+        need = tmp_bytes;
+        HIP_CHECK(rocprim::radix_sort_pairs(tmp.p, need, dk, dv, (size_t)nv, 0, 64, s));
+        // bucket keys in the order of the first sort, then the (stable) sort by bucket
+        hipLaunchKernelGGL(lcx_gather2_u64_kernel, gv, b, 0, s, bkey.p, dv.current(), slot.p, nv, b1a.p);
+        hipLaunchKernelGGL(lcx_iota_kernel, gv, b, 0, s, q2a.p, nv);
+        rocprim::double_buffer<uint64_t> db(b1a.p, b1b.p);
+        rocprim::double_buffer<uint32_t> dq(q2a.p, q2b.p);
+        need = tmp_bytes;
+        HIP_CHECK(rocprim::radix_sort_pairs(tmp.p, need, db, dq, (size_t)nv, 0, 2 * r.seed_k + 1, s));
+        hipLaunchKernelGGL(lcx_place_kernel, gv, b, 0, s, r.dev, (uint32_t)r0, nv, dk.current(), dv.current(), dq.current(), slot.p, key.p, rowpos.p);
+        hipLaunchKernelGGL(lcx_tail_kernel, gv, b, 0, s, r.dev, (uint32_t)r0, nv, db.current(), slot.p, key.p, r.seed.p);
+        HIP_CHECK(hipGetLastError());
+      }
+      covered += nv;
+      nchunks++;
+      r0 = r1;
+    }
+    HIP_CHECK(hipStreamSynchronize(s));
+    if (verbose) fprintf(stderr, "[awry replica %d] left-context index: %llu of %llu rows in buckets of 2..%u rows, %llu chunks of <= %llu rows\n", r.device,
+                         (unsigned long long)covered, (unsigned long long)N, max_bucket, (unsigned long long)nchunks, (unsigned long long)chunk);
+  }
+  for (int t = 1; t <= 7; t++)
+    hipLaunchKernelGGL(lcx_sample_kernel, dim3(grid_for(r, lev_n[t], 256)), dim3(256), 0, s, key.p, N, t, inner.p + lev_off[t], lev_n[t]);
+  HIP_CHECK(hipGetLastError());
+  HIP_CHECK(hipStreamSynchronize(s));
+  r.lcx_key = std::move(key);
+  r.lcx_rowpos = std::move(rowpos);
+  r.lcx_inner = std::move(inner);
+  r.dev.lcx_key = r.lcx_key.p;
+  r.dev.lcx_rowpos = r.lcx_rowpos.p;
+  r.dev.lcx_inner = r.lcx_inner.p;
+  for (int t = 0; t < 8; t++) r.dev.lcx_off[t] = (uint32_t)lev_off[t];
+  if (verbose) fprintf(stderr, "[awry replica %d] left-context index built in %.2f s (%.1f GB)\n", r.device,
+                       std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count(), resident / 1e9);
+  return true;
+}
 
 // Position seeds are kept exactly while they pay: nucleotide replica with the verify accelerators resident and a table
 // sparse enough for the two-phase schedules (the kernels of those schedules settle a singleton from the text and never
@@ -468,7 +594,14 @@ void sync_seed_mode(awry_index* ix, Replica& r) {
   // generic kernel, then finishes singletons against the text)
   const bool want = !off && narrow(h) && r.seed_k > 0 && r.seed.p && r.dense_ratio == 1 && r.dense_sa.p &&
                     (nt ? (r.dev.text4 && (1ull << (2 * r.seed_k)) / 3 >= h.bwt_len) : r.dev.text8 != nullptr);
-  if (want == (r.dev.seed_pos != 0)) return;
+  const bool want_lcx = want && nt && lcx_wanted(ix);
+  if (want == (r.dev.seed_pos != 0)) {
+    if (want && want_lcx != (r.dev.lcx_key != nullptr)) {
+      if (want_lcx) build_lcx(ix, r);
+      else { build_seed(ix, r, r.seed_k); sync_seed_mode(ix, r); }  // (the table carries the index's flags: a fresh one, then position seeds again)
+    }
+    return;
+  }
   if (!want) {  // rows again: rebuild (the row of a position is not recoverable without an inverse SA)
     build_seed(ix, r, r.seed_k);
     return;
@@ -483,6 +616,7 @@ void sync_seed_mode(awry_index* ix, Replica& r) {
   HIP_CHECK(hipGetLastError());
   HIP_CHECK(hipStreamSynchronize(r.stream));
   r.dev.seed_pos = 1;
+  if (want_lcx) build_lcx(ix, r);
 }
 
 std::unique_ptr<Replica> make_replica(awry_index* ix, int device) {
@@ -2588,6 +2722,20 @@ int awry_set_verify_kmers(awry_index_t* idx, int on) {
     for (auto& r : idx->reps) r->verify_kmers = on != 0;
   });
 }
+int awry_set_lcx(awry_index_t* idx, int on) {
+  return guarded([&] {
+    require(idx != nullptr, "null index");
+    idx->lcx_request = on ? -1 : 0;
+    for (size_t s = 0; s < idx->reps.size(); s++) sync_seed_mode(idx, replica(idx, (int)s));
+  });
+}
+int awry_lcx_enabled(const awry_index_t* idx) { return idx && !idx->reps.empty() && idx->reps[0]->dev.lcx_key != nullptr; }
+int awry_debug_lcx(const awry_index_t* idx, int slot, const void** d_keys, const void** d_rowpos) {
+  if (!idx || slot < 0 || slot >= (int)idx->reps.size() || !d_keys || !d_rowpos) return AWRY_ERR_ARG;
+  *d_keys = idx->reps[slot]->lcx_key.p;
+  *d_rowpos = idx->reps[slot]->lcx_rowpos.p;
+  return AWRY_OK;
+}
 const void* awry_debug_dense_sa(const awry_index_t* idx, int slot) {
   return idx && slot >= 0 && slot < (int)idx->reps.size() ? (const void*)idx->reps[slot]->dense_sa.p : nullptr;
 }
@@ -2699,6 +2847,14 @@ int awry_dev_memset(awry_index_t* idx, int slot, void* d_dst, int value, uint64_
 }
 int awry_dev_synchronize(awry_index_t* idx, int slot) {
   return guarded([&] { replica(idx, slot); HIP_CHECK(hipDeviceSynchronize()); });
+}
+int awry_dev_stream_copy(awry_index_t* idx, int slot, void* d_dst, const void* d_src, uint64_t bytes, void* stream) {
+  return guarded([&] {
+    Replica& r = replica(idx, slot);
+    require(d_dst && d_src && bytes % 16 == 0, "stream copy needs device pointers and a multiple of 16 bytes");
+    hipLaunchKernelGGL(stream_copy_kernel, dim3((unsigned)r.num_cus * 16), dim3(256), 0, (hipStream_t)stream, (const uint4*)d_src, (uint4*)d_dst, bytes / 16);
+    HIP_CHECK(hipGetLastError());
+  });
 }
 int awry_dev_timer_begin(awry_index_t* idx, int slot, void* stream) {
   return guarded([&] { Replica& r = replica(idx, slot); HIP_CHECK(hipEventRecord(r.ev0, (hipStream_t)stream)); });

@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <atomic>
 #include <condition_variable>
+#include <vector>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -49,47 +50,67 @@ unsigned effective_cpus() {
   return std::max(1u, std::min(n, 64u));
 }
 
+// Several jobs may be in flight at once -- one per replica thread of a batch call over N replicas, which pack their
+// shards concurrently: a job is a counter over [0, n) posted in a slot; the posting thread works on its own job, and
+// every pool thread takes items from whichever posted job still has some, so the pool's threads split themselves between
+// the replicas by demand (round 2's pool ran one job at a time, the replicas taking turns).
 struct HostPool::Impl {
+  struct Job {
+    const std::function<void(uint64_t)>* fn = nullptr;
+    uint64_t n = 0;
+    std::atomic<uint64_t> next{0}, finished{0};
+    std::atomic<int> refs{0};  // pool threads inside this job
+    std::mutex emu;
+    std::exception_ptr err;
+  };
+  static constexpr int SLOTS = 32;
   std::vector<std::thread> workers;
-  std::mutex job_mu;  // one job at a time
-  std::mutex mu;
-  std::condition_variable cv_start, cv_done;
-  const std::function<void(uint64_t)>* fn = nullptr;
-  uint64_t n = 0;
-  std::atomic<uint64_t> next{0};
-  std::atomic<uint64_t> generation{0};
-  unsigned active = 0;  // workers that have not yet checked out of the current job
+  std::mutex slot_mu;                 // guards slot[] and the taking of a reference
+  Job* slot[SLOTS] = {nullptr};
+  std::mutex mu;                      // sleeping workers
+  std::condition_variable cv;
+  std::atomic<uint64_t> epoch{0};     // bumped whenever a job is posted
   bool stop = false;
-  std::exception_ptr err;
 
-  void drain(const std::function<void(uint64_t)>& f, uint64_t total) {
+  static void work(Job& j) {
     for (;;) {
-      const uint64_t i = next.fetch_add(1, std::memory_order_relaxed);
-      if (i >= total) break;
+      const uint64_t i = j.next.fetch_add(1, std::memory_order_relaxed);
+      if (i >= j.n) break;
       try {
-        f(i);
+        (*j.fn)(i);
       } catch (...) {
-        std::lock_guard<std::mutex> lk(mu);
-        if (!err) err = std::current_exception();
+        std::lock_guard<std::mutex> lk(j.emu);
+        if (!j.err) j.err = std::current_exception();
       }
+      j.finished.fetch_add(1, std::memory_order_release);
     }
   }
 
+  Job* take(int s) {  // a reference to the job in slot s if it still has items to hand out
+    std::lock_guard<std::mutex> lk(slot_mu);
+    Job* j = slot[s];
+    if (!j || j->next.load(std::memory_order_relaxed) >= j->n) return nullptr;
+    j->refs.fetch_add(1, std::memory_order_acq_rel);
+    return j;
+  }
+
   void worker() {
-    uint64_t seen = 0;
     for (;;) {
-      // a batch call issues jobs back to back: spin briefly before going to sleep on the condition variable
-      for (int spin = 0; spin < 4000 && generation.load(std::memory_order_acquire) == seen; spin++) _mm_pause();
+      const uint64_t e = epoch.load(std::memory_order_acquire);
+      bool did = false;
+      for (int s = 0; s < SLOTS; s++)
+        if (Job* j = take(s)) {
+          work(*j);
+          j->refs.fetch_sub(1, std::memory_order_acq_rel);
+          did = true;
+        }
+      if (did) continue;
+      // a batch call posts jobs back to back: spin briefly before going to sleep on the condition variable
+      for (int spin = 0; spin < 4000 && epoch.load(std::memory_order_acquire) == e; spin++) _mm_pause();
+      if (epoch.load(std::memory_order_acquire) != e) continue;
       std::unique_lock<std::mutex> lk(mu);
-      cv_start.wait(lk, [&] { return stop || generation.load(std::memory_order_acquire) != seen; });
+      cv.wait(lk, [&] { return stop || epoch.load(std::memory_order_acquire) != e; });
       if (stop) return;
-      seen = generation.load(std::memory_order_acquire);
-      const std::function<void(uint64_t)>* f = fn;
-      const uint64_t total = n;
-      lk.unlock();
-      drain(*f, total);
-      lk.lock();
-      if (--active == 0) cv_done.notify_one();
     }
   }
 };
@@ -108,8 +129,9 @@ HostPool::~HostPool() {
   {
     std::lock_guard<std::mutex> lk(impl_->mu);
     impl_->stop = true;
+    impl_->epoch.fetch_add(1, std::memory_order_release);
   }
-  impl_->cv_start.notify_all();
+  impl_->cv.notify_all();
   for (auto& w : impl_->workers) w.join();
   delete impl_;
 }
@@ -128,26 +150,35 @@ void HostPool::run(uint64_t n, const std::function<void(uint64_t)>& fn) {
     for (uint64_t i = 0; i < n; i++) fn(i);
     return;
   }
-  std::lock_guard<std::mutex> job(p.job_mu);
+  Impl::Job job;
+  job.fn = &fn;
+  job.n = n;
+  int mine = -1;
+  {
+    std::lock_guard<std::mutex> lk(p.slot_mu);
+    for (int s = 0; s < Impl::SLOTS && mine < 0; s++)
+      if (!p.slot[s]) { p.slot[s] = &job; mine = s; }
+  }
+  if (mine < 0) {  // every slot taken (more than 32 concurrent callers): inline
+    for (uint64_t i = 0; i < n; i++) fn(i);
+    return;
+  }
   {
     std::lock_guard<std::mutex> lk(p.mu);
-    p.fn = &fn;
-    p.n = n;
-    p.next.store(0, std::memory_order_relaxed);
-    p.active = (unsigned)p.workers.size();
-    p.err = nullptr;
-    p.generation.fetch_add(1, std::memory_order_release);
+    p.epoch.fetch_add(1, std::memory_order_release);
   }
-  p.cv_start.notify_all();
-  p.drain(fn, n);
-  std::unique_lock<std::mutex> lk(p.mu);
-  p.cv_done.wait(lk, [&] { return p.active == 0; });
-  if (p.err) {
-    std::exception_ptr e = p.err;
-    p.err = nullptr;
-    lk.unlock();
-    std::rethrow_exception(e);
+  p.cv.notify_all();
+  Impl::work(job);
+  {
+    std::lock_guard<std::mutex> lk(p.slot_mu);  // no new references after this
+    p.slot[mine] = nullptr;
   }
+  // the items other threads are still finishing (the tail of the job: short)
+  for (unsigned spins = 0; job.finished.load(std::memory_order_acquire) < n || job.refs.load(std::memory_order_acquire) != 0; spins++) {
+    if (spins < 4000) _mm_pause();
+    else std::this_thread::yield();  // (a helper was descheduled inside its last item)
+  }
+  if (job.err) std::rethrow_exception(job.err);
 }
 
 void HostPool::run_ranges(uint64_t n, uint64_t grain, const std::function<void(uint64_t, uint64_t)>& fn) {

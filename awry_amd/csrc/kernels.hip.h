@@ -723,6 +723,17 @@ __global__ __launch_bounds__(256) void count_aa_kmer_probe_kernel(DevIndex ix, c
   if (threadIdx.x == 0) ql.count[blockIdx.x] = s_count;
 }
 
+// measurement aid: device-to-device copy, 16 bytes per lane per step (the streaming rate the roofline object prints next to
+// the nominal HBM peak)
+__global__ __launch_bounds__(256) void stream_copy_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, uint64_t n16) {
+  typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+  const v4u* __restrict__ s4 = reinterpret_cast<const v4u*>(src);
+  v4u* __restrict__ d4 = reinterpret_cast<v4u*>(dst);
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride)
+    __builtin_nontemporal_store(__builtin_nontemporal_load(&s4[i]), &d4[i]);
+}
+
 // profiling aid: an empty kernel whose grid size names a phase of a benchmark run, so that the per-dispatch rows of a
 // rocprofv3 counter pass (which cannot be combined with marker tracing on this pool) can be cut into those phases
 __global__ void phase_marker_kernel() {}
@@ -1088,6 +1099,10 @@ __device__ __forceinline__ uint32_t verify_part(const uint32_t* __restrict__ tex
   return text_window_differs(text_window_load(text4, g + (uint64_t)j0, len - j0), qword);
 }
 
+}  // namespace awry
+#include "lcx.hip.h"
+namespace awry {
+
 // "quad4" variant of the hot kernel: a quad owns GROUPS of 4 consecutive queries (32 contiguous bytes in and out).
 // Lane t of the quad loads query 4m+t and keeps result 4m+t, so the group is read with one 32-B request and
 // written back as one whole 32-B sector; the strided kernel above writes every 8-B count on its own, which
@@ -1226,6 +1241,8 @@ __global__ __launch_bounds__(256) void count_nt2_quad4_kernel(DevIndex ix, const
 //     queries that need LF steps are appended (wave ballot + one atomic per wave) to a compact survivor list;
 //   phase 2 (count_nt2_resume_kernel): the quad machinery on the survivors only, resuming from the probed range.
 constexpr int VMULTI = 4;  // seed ranges of up to this many rows are verified candidate by candidate in phase 1
+constexpr int LCX_LANE_ROWS = 4;  // buckets of the left-context index with up to this many rows are decided by a lane of phase 1
+constexpr int LCX_TAIL_MAX = 16;  // more incomplete entries than this in a bucket: its queries take LF steps
 
 struct Nt2Survivors {
   uint64_t* w;                 // query words
@@ -1262,8 +1279,11 @@ __global__ __launch_bounds__(256) void count_nt2_probe_kernel(DevIndex ix, const
   const bool pos = VERIFY && ix.seed_pos;   // singleton entries hold SA[row]: no SA read, and no row to step from
   const int cx = (int)ix.ctx_extra, clen = SEED_CTX_LEN + cx;  // letters in front of the occurrence a context entry holds
   const bool verify = VERIFY && (i0 >= 3 || (pos && i0 >= 1));
+  // left-context index resident: a seed range of 2+ rows is told apart by the keys of its bucket -- up to LCX_LANE_ROWS rows
+  // by this lane (their keys are 32 contiguous bytes), more by the quads of phase 2 -- and takes no LF step
+  const bool lcx = VERIFY && ix.lcx_key != nullptr && i0 >= 1;
   int vcount = 0;  // wave-uniform fill of this wave's queue
-  uint32_t t_vsa = 0, t_vtxt = 0;
+  uint32_t t_vsa = 0, t_vtxt = 0, t_lcx = 0;
   auto drain = [&](int base, int cnt) {  // entries [base, base + cnt) of the queue, cnt <= 128: two per lane
     uint64_t w[2];
     uint32_t q[2], sp[2], nc[2], vp[2];
@@ -1277,12 +1297,23 @@ __global__ __launch_bounds__(256) void count_nt2_probe_kernel(DevIndex ix, const
       sp[h] = on[h] ? s_vsp[VERIFY ? wv_id : 0][s] : 0;
       nc[h] = on[h] ? s_vn[VERIFY ? wv_id : 0][s] : 0;
       vp[h] = sp[h];  // position seed: the entry is the candidate's text position already
-      if (on[h] && !(pos && nc[h] == 1u)) { vp[h] = ix.dense_sa[sp[h]]; if (TALLY) t_vsa++; }
+      if (on[h] && !(nc[h] & 0x80u) && !(pos && nc[h] == 1u)) { vp[h] = ix.dense_sa[sp[h]]; if (TALLY) t_vsa++; }
     }
 #pragma unroll
     for (int h = 0; h < 2; h++) {
       if (!on[h]) continue;
       uint64_t value = 0;
+      if (nc[h] & 0x80u) {  // a bucket of the left-context index: the rows whose key starts with the query's i0 letters
+        const uint64_t want = (w[h] & ((1ull << (2 * i0)) - 1)) << (64 - 2 * i0);
+        const uint32_t rows = nc[h] & 0x7Fu;
+        const uint64_t* __restrict__ kp = ix.lcx_key + sp[h];
+        const uint64_t k0 = kp[0], k1 = kp[1], k2 = rows > 2u ? kp[2] : ~want, k3 = rows > 3u ? kp[3] : ~want;  // (2+ rows; one line, mostly)
+        const int sh = 64 - 2 * i0;
+        value = (((k0 ^ want) >> sh) == 0) + (((k1 ^ want) >> sh) == 0) + (((k2 ^ want) >> sh) == 0) + (((k3 ^ want) >> sh) == 0);
+        if (TALLY) t_lcx++;
+        counts[q[h]] = value;
+        continue;
+      }
       for (uint32_t c = 0; c < nc[h]; c++) {  // the rows of a range are neighbours in the dense SA: mostly one line
         const uint32_t p = c ? ix.dense_sa[sp[h] + c] : vp[h];
         if (TALLY && c) t_vsa++;
@@ -1315,7 +1346,7 @@ __global__ __launch_bounds__(256) void count_nt2_probe_kernel(DevIndex ix, const
       const uint64_t q = qv[h], w = wv[h];
       const SeedEntry e = ev[h];
       const uint32_t cnt = seed_cnt(e);
-      bool survivor = false, queued = false;
+      bool survivor = false, queued = false, lcx_q = false;
       uint64_t value = 0;
       if (valid) {
         if (cnt == SEED_CNT_SAT) survivor = true;
@@ -1331,6 +1362,11 @@ __global__ __launch_bounds__(256) void count_nt2_probe_kernel(DevIndex ix, const
           const uint32_t nc = (uint32_t)(w >> (2 * (i0 - 1))) & 3u;
           survivor = seed_sym(e) == (int)(nc == 3u ? 5u : nc + 1u);  // else BWT[sp] is not the next letter: absent
           if (verify && survivor) { queued = true; survivor = false; }
+        } else if (lcx && !(e.cnt & (SEED_LCX_NONE | SEED_LCX_TAIL)) && cnt <= (uint32_t)LCX_LANE_ROWS) {
+          queued = true;  // the keys of the bucket's few rows decide (one line, no SA, no text)
+          lcx_q = true;
+        } else if (lcx && !(e.cnt & SEED_LCX_NONE)) {
+          survivor = true;  // phase 2 searches the bucket's keys
         } else if (verify && cnt <= (uint32_t)VMULTI && (int)(3u * cnt) <= i0 + 2) {  // (+ 2: two rows with 4 or 5 letters left are cheaper here than as survivors)
           queued = true;  // a handful of candidate rows: each is checked against the text here, none goes to phase 2
         } else survivor = true;
@@ -1344,7 +1380,7 @@ __global__ __launch_bounds__(256) void count_nt2_probe_kernel(DevIndex ix, const
             s_vw[wv_id][s] = w;
             s_vsp[wv_id][s] = cnt == 1u && pos ? seed_position(e, cx) : e.sp;
             s_vq[wv_id][s] = (uint32_t)q;
-            s_vn[wv_id][s] = (uint8_t)cnt;
+            s_vn[wv_id][s] = (uint8_t)(cnt | (lcx_q ? 0x80u : 0u));
           }
           vcount += (int)__popcll(qm);
           __builtin_amdgcn_wave_barrier();
@@ -1363,7 +1399,7 @@ __global__ __launch_bounds__(256) void count_nt2_probe_kernel(DevIndex ix, const
         if (survivor) {
           const uint64_t s = region + slot0 + (uint64_t)__popcll(sm & lane_lt);
           sv.w[s] = w;
-          sv.range[s] = (uint64_t)e.sp | ((uint64_t)cnt << 32);
+          sv.range[s] = (uint64_t)e.sp | ((uint64_t)(cnt | (e.cnt & (SEED_LCX_NONE | SEED_LCX_TAIL))) << 32);  // (flags of a 2+ row entry)
           sv.q[s] = (uint32_t)q;
         }
       }
@@ -1374,9 +1410,10 @@ __global__ __launch_bounds__(256) void count_nt2_probe_kernel(DevIndex ix, const
   if (threadIdx.x == 0) sv.count[blockIdx.x] = s_count;
   if (TALLY) {
     if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&tally[0], (unsigned long long)n);
-    if (VERIFY && (t_vsa | t_vtxt)) {
+    if (VERIFY && (t_vsa | t_vtxt | t_lcx)) {
       atomicAdd(&tally[3], (unsigned long long)t_vsa);
       atomicAdd(&tally[4], (unsigned long long)t_vtxt);
+      atomicAdd(&tally[6], (unsigned long long)t_lcx);
     }
   }
 }
@@ -1395,25 +1432,34 @@ __global__ __launch_bounds__(256) void count_nt2_resume_kernel(DevIndex ix, Nt2S
   const uint64_t* __restrict__ blocks = ix.blocks;
   const int k = ix.seed_k;
   const int verify_after = (int)ix.verify_after;
+  const bool lcx = VERIFY && ix.lcx_key != nullptr;
   const uint32_t cA = (uint32_t)ix.prefix_sums[1], cC = (uint32_t)ix.prefix_sums[2], cG = (uint32_t)ix.prefix_sums[3],
                  cN = (uint32_t)ix.prefix_sums[4], cT = (uint32_t)ix.prefix_sums[5], cEnd = (uint32_t)ix.prefix_sums[6];
   bool have = r < ns, fresh = true;
   uint64_t w = 0;
   uint32_t sp = 1, ep = 0, qidx = 0;
   int i = 0, steps_done = 0;
-  int mode = 0, vj = 0;  // verify: 0 = LF steps, 1 = read SA of candidate vj, 2 = compare its text window
+  // 0 = LF steps, 1 = read SA of candidate vj, 2 = compare its text window (seed-and-verify);
+  // left-context index: 3 = read the number of incomplete entries, 4 = search the keys, 5 = text position of incomplete
+  // entry vj, 6 = compare it with the text
+  int mode = 0, vj = 0;
   uint32_t vhits = 0, vp = 0;
-  uint32_t t_step = 0, t_blk = 0, t_vsa = 0, t_vtxt = 0;
+  LcxQ lq{0, 0, 0, 0, -1};
+  uint64_t qlo = 0, qhi = 0;
+  uint32_t b_cnt = 0, b_inc = 0;  // rows / incomplete rows of the bucket being searched
+  uint32_t t_step = 0, t_blk = 0, t_vsa = 0, t_vtxt = 0, t_lcx = 0, t_rp = 0;
   while (__any(have)) {
     if (have) {
       bool finished = false;
       uint64_t out_count = 0;
-      if (!VERIFY || mode == 0) {
+      if (mode == 0) {
         if (fresh) {  // the record replaces the seed probe; the first step follows in the same iteration
           w = sv.w[region + r];
           const uint64_t rg = sv.range[region + r];
           qidx = sv.q[region + r];
-          const uint32_t cnt = (uint32_t)(rg >> 32);
+          const uint32_t cf = (uint32_t)(rg >> 32), cnt = cf & SEED_CNT_SAT;
+          steps_done = 0;
+          fresh = false;
           if (cnt == SEED_CNT_SAT) {
             const uint32_t c = (uint32_t)(w >> (2 * (L - 1))) & 3u;
             sp = c == 0 ? cA : (c == 1 ? cC : (c == 2 ? cG : cT));
@@ -1423,40 +1469,73 @@ __global__ __launch_bounds__(256) void count_nt2_resume_kernel(DevIndex ix, Nt2S
             sp = (uint32_t)rg;
             ep = sp + cnt - 1u;
             i = L - k;
+            if (lcx && cnt >= 2u && !(cf & SEED_LCX_NONE) && i > 0) {  // the bucket's keys tell its rows apart: no LF step
+              b_cnt = cnt;
+              b_inc = 0;
+              lcx_thresholds(w, i, &qlo, &qhi);
+              vhits = 0;
+              if (cf & SEED_LCX_TAIL) mode = 3;
+              else { lcx_begin(lq, sp, cnt); mode = 4; }
+            }
           }
-          steps_done = 0;
-          fresh = false;
         }
-        // a probed singleton (its BWT symbol already matched the next letter) goes straight to the text
-        const bool skip_step = VERIFY && i > 0 && sp <= ep && verify_now(ep - sp + 1u, i, steps_done, verify_after);
-        if (i > 0 && sp <= ep && !skip_step) {
-          i--;
-          const uint32_t c = (uint32_t)(w >> (2 * i)) & 3u;
-          const uint32_t cl = c == 0 ? cA : (c == 1 ? cC : (c == 2 ? cG : cT));
-          if (TALLY) { t_step++; t_blk += ((sp - 1) >> 8) == (ep >> 8) ? 1u : 2u; }
-          quad_step(blocks, cl, sp, ep, c, l);
-          steps_done++;
-        }
-        if (sp > ep || i == 0) {
-          finished = true;
-          out_count = sp > ep ? 0ull : (uint64_t)(ep - sp) + 1ull;
-        } else if (VERIFY) {
-          const uint32_t cnt = ep - sp + 1u;
-          if (verify_now(cnt, i, steps_done, verify_after)) { mode = 1; vj = 0; vhits = 0; }
+        if (mode == 0) {
+          // a probed singleton (its BWT symbol already matched the next letter) goes straight to the text
+          const bool skip_step = VERIFY && i > 0 && sp <= ep && verify_now(ep - sp + 1u, i, steps_done, verify_after);
+          if (i > 0 && sp <= ep && !skip_step) {
+            i--;
+            const uint32_t c = (uint32_t)(w >> (2 * i)) & 3u;
+            const uint32_t cl = c == 0 ? cA : (c == 1 ? cC : (c == 2 ? cG : cT));
+            if (TALLY) { t_step++; t_blk += ((sp - 1) >> 8) == (ep >> 8) ? 1u : 2u; }
+            quad_step(blocks, cl, sp, ep, c, l);
+            steps_done++;
+          }
+          if (sp > ep || i == 0) {
+            finished = true;
+            out_count = sp > ep ? 0ull : (uint64_t)(ep - sp) + 1ull;
+          } else if (VERIFY) {
+            const uint32_t cnt = ep - sp + 1u;
+            if (verify_now(cnt, i, steps_done, verify_after)) { mode = 1; vj = 0; vhits = 0; }
+          }
         }
       } else if (mode == 1) {
         vp = ix.dense_sa[sp + (uint32_t)vj];
         if (TALLY) t_vsa++;
         if (vp >= (uint32_t)i) mode = 2;
         else vj++;
-      } else {
+      } else if (mode == 2) {
         const uint32_t bad = quad_sum(verify_part(ix.text4, (uint64_t)vp - (uint64_t)i, i, 0, l, w));
         if (TALLY) t_vtxt++;
         if (!bad) vhits++;
         vj++;
         mode = 1;
+      } else if (mode == 3) {  // the key slot of the bucket's last row holds the number of incomplete entries
+        b_inc = (uint32_t)ix.lcx_key[sp + b_cnt - 1u];
+        if (TALLY) t_lcx++;
+        if (b_inc > (uint32_t)LCX_TAIL_MAX) { mode = 0; b_cnt = 0; }  // (too many to check one by one: LF steps after all)
+        else { lcx_begin(lq, sp, b_cnt - b_inc); mode = 4; }
+      } else if (mode == 4) {
+        const int lines = lcx_quad_step(ix, lq, qlo, qhi, l);
+        if (TALLY) t_lcx += (uint32_t)lines;
+        if (lq.t < 0) {
+          vhits = lq.a1 - lq.a0;
+          if (b_inc) { mode = 5; vj = 0; }
+          else { finished = true; out_count = vhits; }
+        }
+      } else if (mode == 5) {  // incomplete entry vj: its text position
+        vp = (uint32_t)ix.lcx_rowpos[sp + (b_cnt - b_inc) + (uint32_t)vj];
+        if (TALLY) t_rp++;
+        if (vp >= (uint32_t)i) mode = 6;
+        else vj++;
+      } else {
+        const uint32_t bad = quad_sum(verify_part(ix.text4, (uint64_t)vp - (uint64_t)i, i, 0, l, w));
+        if (TALLY) t_vtxt++;
+        if (!bad) vhits++;
+        vj++;
+        mode = 5;
       }
       if (VERIFY && mode == 1 && vj > (int)(ep - sp)) { finished = true; out_count = vhits; }
+      if (mode == 5 && vj >= (int)b_inc) { finished = true; out_count = vhits; }
       if (finished) {
         if (l == 0) counts[qidx] = out_count;
         r += 64;
@@ -1472,6 +1551,8 @@ __global__ __launch_bounds__(256) void count_nt2_resume_kernel(DevIndex ix, Nt2S
     if (VERIFY) {
       atomicAdd(&tally[3], (unsigned long long)t_vsa);
       atomicAdd(&tally[4], (unsigned long long)t_vtxt);
+      atomicAdd(&tally[6], (unsigned long long)t_lcx);
+      atomicAdd(&tally[7], (unsigned long long)t_rp);
     }
   }
 }
@@ -1841,16 +1922,25 @@ __global__ __launch_bounds__(256) void count_nt2_reads_kernel(DevIndex ix, const
   const uint32_t* __restrict__ text4 = ix.text4;
   const int k = USE_SEED ? ix.seed_k : 1, W = (L + 31) / 32;
   const int verify_after = (int)ix.verify_after;
+  // left-context index (layout.h): a seed range of 2+ rows is narrowed by a search over its bucket's keys -- the 32 letters
+  // left of the seed window in log16(rows) lines -- instead of one LF step per letter; what is left is compared with the text
+  const bool lcx = USE_SEED && VERIFY && ix.lcx_key != nullptr;
   const uint32_t cA = (uint32_t)ix.prefix_sums[1], cC = (uint32_t)ix.prefix_sums[2], cG = (uint32_t)ix.prefix_sums[3],
                  cN = (uint32_t)ix.prefix_sums[4], cT = (uint32_t)ix.prefix_sums[5], cEnd = (uint32_t)ix.prefix_sums[6];
   bool have = LIST ? r < n : q < n, fresh = true;
   uint64_t w = 0;
   uint32_t sp = 1, ep = 0;
   int i = 0, steps_done = 0;
-  // verify state (quad-uniform): mode 0 = LF steps, 1 = read SA of candidate vj, 2 = compare text chunk vc
+  // quad-uniform state: mode 0 = LF steps, 1 = text position of candidate vj, 2 = compare text chunk vc;
+  // left-context index: 3 = number of incomplete entries of the bucket, 4 = search its keys
   int mode = 0, vj = 0, vc = 0;
   uint32_t vmask = 0, vp = 0;
   bool pos_hit = false;  // position seed whose window is the whole read
+  bool cand_lcx = false;  // modes 1 / 2: candidates sp..ep are entries of the left-context index, not rows
+  bool tail_pass = false; // modes 1 / 2: the candidates are the bucket's incomplete entries (after the key search)
+  LcxQ lq{0, 0, 0, 0, -1};
+  uint64_t qlo = 0, qhi = 0;
+  uint32_t b_sp = 0, b_cnt = 0, b_inc = 0, key_hits = 0, key_lb = 0;
   while (__any(have)) {
     if (have) {
       const uint64_t* qw = queries + q * W;
@@ -1895,6 +1985,7 @@ __global__ __launch_bounds__(256) void count_nt2_reads_kernel(DevIndex ix, const
               sp = ep = 0u;  // one candidate, index 0
               vj = 0;
               vmask = 0;
+              cand_lcx = tail_pass = false;
               if (vp >= (uint32_t)i) { mode = 2; vc = 0; }
               else { mode = 1; vj = 1; }  // too close to the text's beginning: no match (finishes below)
             } else {  // start again without the table
@@ -1904,6 +1995,13 @@ __global__ __launch_bounds__(256) void count_nt2_reads_kernel(DevIndex ix, const
               i = Lq - 1;
               w = i > 0 ? qw[(i - 1) >> 5] : 0;
             }
+          } else if (lcx && seeded && scnt >= 2u && scnt != SEED_CNT_SAT && !(e.cnt & SEED_LCX_NONE) && i > 0 && i < 65536) {
+            b_sp = sp;
+            b_cnt = scnt;
+            b_inc = 0;
+            lcx_thresholds(lcx_read_ctx(qw, W, i), i < LCX_CTX ? i : LCX_CTX, &qlo, &qhi);
+            if (e.cnt & SEED_LCX_TAIL) mode = 3;
+            else { lcx_begin(lq, b_sp, b_cnt); mode = 4; }
           }
           fresh = false;
         } else {
@@ -1920,32 +2018,77 @@ __global__ __launch_bounds__(256) void count_nt2_reads_kernel(DevIndex ix, const
           out_count = 1;
           out_rs = (RS_SINGLE << RS_MODE_SHIFT) | (uint64_t)vp;
         } else if (mode != 0) {
-          // a position seed went straight to the text
+          // a position seed went straight to the text / the bucket's keys are searched
         } else if (sp > ep || i == 0) {
           finished = true;
           out_count = sp > ep ? 0ull : (uint64_t)(ep - sp) + 1ull;
           out_rs = (RS_PLAIN << RS_MODE_SHIFT) | sp;
         } else if (VERIFY) {
           const uint32_t cnt = ep - sp + 1u;
-          if (verify_now(cnt, i, steps_done, verify_after) && i < 65536) { mode = 1; vj = 0; vmask = 0; }
+          if (verify_now(cnt, i, steps_done, verify_after) && i < 65536) { mode = 1; vj = 0; vmask = 0; cand_lcx = tail_pass = false; }
         }
-      } else if (mode == 1) {  // text position of candidate row sp + vj
-        vp = dense[sp + (uint32_t)vj];
+      } else if (mode == 1) {  // text position of candidate vj: row sp + vj, or entry sp + vj of the left-context index
+        vp = cand_lcx ? (uint32_t)ix.lcx_rowpos[sp + (uint32_t)vj] : dense[sp + (uint32_t)vj];
         if (vp >= (uint32_t)i) { mode = 2; vc = 0; }
         else vj++;  // the suffix starts too close to the text's beginning to have i symbols in front
-      } else {      // compare window chunk vc of candidate vj
+      } else if (mode == 2) {      // compare window chunk vc of candidate vj
         const uint64_t g = (uint64_t)vp - (uint64_t)i;
         const int wi = 4 * vc + l;
         const uint32_t bad = quad_sum(verify_part(text4, g, i, vc, l, wi < W ? qw[wi] : 0ull));
         if (bad) { vj++; mode = 1; }
         else if (128 * (vc + 1) < i) vc++;
         else { vmask |= 1u << vj; vj++; mode = 1; }
+      } else if (mode == 3) {  // the key slot of the bucket's last row holds the number of incomplete entries
+        b_inc = (uint32_t)ix.lcx_key[b_sp + b_cnt - 1u];
+        // (they can only match a read with fewer than 32 letters left of its seed window; more of them than are worth
+        //  checking one by one: LF steps after all)
+        if (i < LCX_CTX && b_inc > (uint32_t)LCX_TAIL_MAX) mode = 0;
+        else { lcx_begin(lq, b_sp, b_cnt - b_inc); mode = 4; }
+      } else {  // mode 4
+        lcx_quad_step(ix, lq, qlo, qhi, l);
+        if (lq.t < 0) {
+          key_lb = lq.a0;
+          key_hits = lq.a1 - lq.a0;
+          if (i <= LCX_CTX) {
+            // the keys hold every letter the read has left: the run IS the answer, but for the bucket's incomplete entries
+            if (b_inc && i < LCX_CTX) {  // (at most LCX_TAIL_MAX <= 32 of them: vmask has a bit each)
+              sp = b_sp + (b_cnt - b_inc); ep = b_sp + b_cnt - 1u;
+              cand_lcx = tail_pass = true;
+              mode = 1; vj = 0; vmask = 0;
+            } else if (!range_start || key_hits <= 8u) {
+              finished = true;
+              out_count = key_hits;
+              out_rs = key_hits ? ((RS_LCX << RS_MODE_SHIFT) | (uint64_t)key_lb | ((uint64_t)i << 32) | ((uint64_t)((1u << key_hits) - 1u) << 48))
+                                : ((RS_PLAIN << RS_MODE_SHIFT) | 1ull);
+            } else mode = 0;  // the locate pass wants the rows of a larger range: LF steps from the seed range
+          } else if (key_hits == 0u) {
+            finished = true;
+            out_rs = (RS_PLAIN << RS_MODE_SHIFT) | 1ull;
+          } else if (key_hits <= 8u) {  // the entries that agree on 32 letters: the rest of each is compared with the text
+            sp = key_lb; ep = key_lb + key_hits - 1u;
+            cand_lcx = true; tail_pass = false;
+            mode = 1; vj = 0; vmask = 0;
+          } else mode = 0;  // too many candidates still (a young or exact repeat): LF steps from the seed range
+          if (mode == 0) { sp = b_sp; ep = b_sp + b_cnt - 1u; }
+        }
       }
       if (VERIFY && mode == 1 && vj > (int)(ep - sp)) {  // all candidates checked
-        finished = true;
-        out_count = (uint64_t)__popc(vmask);
-        if (ep == sp && vmask) out_rs = (RS_SINGLE << RS_MODE_SHIFT) | ((uint64_t)vp - (uint64_t)i);
-        else out_rs = (RS_MULTI << RS_MODE_SHIFT) | (uint64_t)sp | ((uint64_t)i << 32) | ((uint64_t)vmask << 48);
+        if (tail_pass) {  // the bucket's incomplete entries: they add to the run the keys selected
+          const uint32_t th = (uint32_t)__popc(vmask);
+          tail_pass = cand_lcx = false;
+          if (!range_start || (th == 0u && key_hits <= 8u)) {
+            finished = true;
+            out_count = (uint64_t)key_hits + th;
+            out_rs = key_hits ? ((RS_LCX << RS_MODE_SHIFT) | (uint64_t)key_lb | ((uint64_t)i << 32) | ((uint64_t)((1u << key_hits) - 1u) << 48))
+                              : ((RS_PLAIN << RS_MODE_SHIFT) | 1ull);
+          } else { mode = 0; sp = b_sp; ep = b_sp + b_cnt - 1u; }
+        } else {
+          finished = true;
+          out_count = (uint64_t)__popc(vmask);
+          if (ep == sp && vmask) out_rs = (RS_SINGLE << RS_MODE_SHIFT) | ((uint64_t)vp - (uint64_t)i);
+          else out_rs = ((cand_lcx ? RS_LCX : RS_MULTI) << RS_MODE_SHIFT) | (uint64_t)sp | ((uint64_t)i << 32) | ((uint64_t)vmask << 48);
+          cand_lcx = false;
+        }
       }
       if (finished) {
         if (l == 0) {
@@ -2331,6 +2474,22 @@ __global__ __launch_bounds__(256) void locate_tile_kernel(DevIndex ix, const uin
           for (uint64_t t2 = 0; t2 < j; t2++) mask &= mask - 1;  // drop the j lowest set bits
           const uint32_t cand = (uint32_t)__ffs((int)mask) - 1u;
           gd = (uint64_t)ix.dense_sa[(uint32_t)rs + cand] - ((rs >> 32) & 0xffffull);
+        } else if (rmode == RS_LCX) {
+          // matched entries of the left-context index (up to 8 neighbours of lcx_rowpos: one line): hit j is the one with
+          // the (j + 1)-th smallest BWT row -- ascending row order inside a query, src/fm_index.rs:521
+          const uint32_t mask = (uint32_t)(rs >> 48) & 0xffu, base = (uint32_t)rs;
+          uint64_t rp[8];
+#pragma unroll
+          for (int c = 0; c < 8; c++) rp[c] = (mask >> c) & 1u ? ix.lcx_rowpos[base + c] : ~0ull;
+          uint64_t pick = 0;
+#pragma unroll
+          for (int c = 0; c < 8; c++) {
+            uint32_t below = 0;
+#pragma unroll
+            for (int d = 0; d < 8; d++) below += (rp[d] >> 32) < (rp[c] >> 32) ? 1u : 0u;
+            if (((mask >> c) & 1u) && below == (uint32_t)j) pick = rp[c];
+          }
+          gd = (pick & 0xffffffffull) - ((rs >> 32) & 0xffffull);
         } else {
           row = rs + j;
         }

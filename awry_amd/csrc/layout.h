@@ -88,6 +88,9 @@ AWRY_HD uint64_t seed_full_ctx(SeedEntry e, int extra) {
   return (extra ? (uint64_t)(e.sp >> (32 - 2 * extra)) : 0ull) | ((uint64_t)seed_ctx(e) << (2 * extra));
 }
 AWRY_HD int seed_sym(SeedEntry e) { return (int)(e.cnt >> 29); }
+// Entries of 2+ rows leave bits 29..31 of cnt unused; while the left-context index (DevIndex::lcx_key, below) is resident:
+constexpr uint32_t SEED_LCX_TAIL = 0x20000000u;  // the bucket's last rows have an incomplete left context (see LCX below)
+constexpr uint32_t SEED_LCX_NONE = 0x40000000u;  // the bucket is not in the left-context index (too many rows): LF steps
 
 // Seed entry of an index with 2^32 rows or more ("wide rows": the packed kernels then carry 64-bit rows): the exact range
 // of a k-mer as (start row, count); final-level entries of singleton ranges also hold the symbol index stored in the BWT
@@ -155,7 +158,24 @@ struct DevIndex {
   const uint32_t* sa_nblock;  // SA of every row whose suffix starts with N (rows [C[N], C[T])), or nullptr: ends locate
                               //   walks that run into an N run, where LF moves by a constant stride and row sampling can
                               //   leave a walk without a sampled row for the length of the run
+  // LCX, the left-context index (device-only accelerator; nullptr when absent).  A seed bucket -- the rows [sp, sp + cnt)
+  // of the suffixes that start with one seed k-mer -- is sorted by what FOLLOWS the k-mer, while backward search has to
+  // tell its rows apart by what PRECEDES it: one LF step (two random block lines) per letter, and a k-mer inside a repeat
+  // family has 10^3..10^5 rows that stay together for dozens of letters.  lcx_key holds, for every row slot of a bucket
+  // of 2+ rows, the 32 letters in front of one of the bucket's suffixes -- text[p - 32 .. p) packed like a query word, so
+  // the letter next to the seed is the most significant -- with the bucket's entries SORTED by that key; lcx_rowpos holds
+  // the same entry's text position p (low word) and its BWT row (high word).  The letters a query has left of its seed
+  // window then select a contiguous run of a bucket's entries: its length is the count (up to 32 letters), its entries are
+  // the candidates to compare with the text (more letters).  Entries whose 32 left letters do not all exist as ACGT sit at
+  // the bucket's end, unsorted (SEED_LCX_TAIL; the key slot of the bucket's last row holds how many).
+  // lcx_inner: every 16^t-th key, t = 1.. (level t at lcx_off[t]): a search runs top-down through one aligned 16-key node
+  // (one 128-B line) per level, masked to the bucket's own rows -- log16(cnt) lines instead of 2 x (letters left).
+  const uint64_t* lcx_key;
+  const uint64_t* lcx_rowpos;
+  const uint64_t* lcx_inner;
+  uint32_t lcx_off[8];
 };
+constexpr int LCX_CTX = 32;  // letters of left context in a key
 
 // encoding of a query's "range start" word handed from the count pass to the locate pass
 constexpr uint64_t RS_MODE_SHIFT = 62;
@@ -163,5 +183,8 @@ constexpr uint64_t RS_PLAIN = 0;   // low bits = first BWT row of the final rang
 constexpr uint64_t RS_MULTI = 1;   // verified candidates: rows sp..sp+7, bit j of mask = candidate j matched;
                                    //   bits 0..31 sp, 32..47 symbols left of the seed part (i), 48..55 mask
 constexpr uint64_t RS_SINGLE = 2;  // one verified match: low 40 bits = text position of the match
+constexpr uint64_t RS_LCX = 3;     // matches found through the left-context index: entries base .. base + 7 of lcx_rowpos, bit j
+                                   //   of mask = entry j matched; bits 0..31 base, 32..47 letters left of the seed (i), 48..55
+                                   //   mask.  The locate pass emits them in ascending BWT row (lcx_rowpos holds each entry's row).
 
 }  // namespace awry

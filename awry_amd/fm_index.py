@@ -427,6 +427,28 @@ class FmIndex:
     def locate_sa_ratio(self) -> int:
         return self._L.awry_locate_sa_ratio(self._h)
 
+    def set_lcx(self, on: bool):
+        """left-context index on / off (performance knob; results do not depend on it)"""
+        _check(self._L.awry_set_lcx(self._h, 1 if on else 0))
+
+    def lcx_enabled(self) -> bool:
+        return bool(self._L.awry_lcx_enabled(self._h))
+
+    def debug_lcx(self, slot=0):
+        """-> (keys uint64[bwt_len], rowpos uint64[bwt_len]) copied from replica `slot`, or None when it is not resident"""
+        k, rp = C.c_void_p(), C.c_void_p()
+        _check(self._L.awry_debug_lcx(self._h, slot, C.byref(k), C.byref(rp)))
+        if not k.value:
+            return None
+        n = self.bwt_len()
+        keys, rowpos = np.empty(n, np.uint64), np.empty(n, np.uint64)
+        _check(self._L.awry_dev_memcpy_d2h(self._h, slot, keys.ctypes.data, k, n * 8))
+        _check(self._L.awry_dev_memcpy_d2h(self._h, slot, rowpos.ctypes.data, rp, n * 8))
+        return keys, rowpos
+
+    def dev_stream_copy(self, d_dst, d_src, nbytes, stream=None, slot=0):
+        _check(self._L.awry_dev_stream_copy(self._h, slot, d_dst, d_src, nbytes, stream))
+
     def set_verify(self, after_steps: int):
         """seed-and-verify for packed nucleotide reads (-1 = off); results do not depend on it"""
         _check(self._L.awry_set_verify(self._h, after_steps))

@@ -35,10 +35,14 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 WORKLOADS = {
-    # name: (text length without '$', records, N fraction)   -- SURVEY.md 8(d) C1/C2/C3 shapes
-    "ecoli": (4_641_652, 1, 0.0),
-    "chr1": (248_956_422, 1, 0.07),
-    "grch38": (3_100_000_000, 25, 0.05),
+    # name: (text length without '$', records, N fraction, composition)   -- SURVEY.md 8(d) C1/C2/C3 shapes
+    "ecoli": (4_641_652, 1, 0.0, "iid"),
+    "chr1": (248_956_422, 1, 0.07, "iid"),
+    "grch38": (3_100_000_000, 25, 0.05, "iid"),
+    # the default: GRCh38's size AND composition -- 43 % of the text in repeat families (300 bp .. 6 kb units, 10^3 .. 10^6
+    # copies, 2 .. 15 % divergence), satellite and tandem arrays, segmental duplications, assembly gaps (tests/synth.py)
+    "grch38-repeats": (3_100_000_000, 25, 0.05, "repeats"),
+    "chr1-repeats": (248_956_422, 1, 0.05, "repeats"),
 }
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 AMINO_TEXT, AMINO_RECORDS, AMINO_NQ, AMINO_L = 90_000_000, 250_000, 10_000_000, 12  # BASELINE.json configs[3]
@@ -111,6 +115,20 @@ class Ctx:
         return a.elapsed_time(b) / reps
 
 
+def workload_text(args, torch, dev, workload=None, n_text=None):
+    """-> (text uint8 incl. '$', record starts, headers, info) of a workload: i.i.d. letters with runs of N (numpy), or the
+    repeat-rich genome-shaped text (generated on the GPU)"""
+    from tests import synth
+    n, n_rec, n_frac, comp = WORKLOADS[workload or args.workload]
+    n = n_text or n
+    if comp == "repeats":
+        text, starts, headers, info = synth.repeat_rich_text(n, 0xA5A50000 + 6, n_rec, device=str(dev))
+        info = {k: v for k, v in info.items() if k != "families"} | {"families": {k: v["copies"] for k, v in info["families"].items()}}
+        return text, starts, headers, dict(info, composition="repeat-rich (tests/synth.repeat_rich_text)")
+    text, starts, headers = synth.make_text(n, 0, 0xA5A50000 + 2, n_rec, n_frac)
+    return text, starts, headers, {"composition": "i.i.d. uniform ACGT", "n_fraction": n_frac, "repeat_fraction": 0.0}
+
+
 def device_sampled_reads(torch, text_d, n_reads, L, seed, amb):
     """n_reads windows of L symbols drawn from the device copy of the text at uniform positions, windows holding the
     ambiguity letter (or the sentinel) skipped -- SURVEY.md 8(d) C3's reads, generated where they are used"""
@@ -147,7 +165,17 @@ def attach_traffic(entry, ms, pmc, phase):
 
 
 # ------------------------------------------------------------------------------------------------ device-resident legs
-def run_variants(ctx, ix, text, batches, nq, L, counts, tally, oi, cores):
+PRESENT_BATCHES = 4  # distinct batches of k-mers from the text, rotated: what one rotation touches (4 x 10 M queries x >= 1 random
+                     # 128-B line each = 5 GB) is many times the 256 MiB Infinity Cache, so its hits cannot flatter rate or traffic
+
+
+def lcx_price(t):
+    """algorithmic bytes of the left-context index work in a census: 32 B per node consulted (the 4 keys a binary search
+    inside a 16-key node compares) + 8 B per (position, row) entry read"""
+    return 32.0 * t[6] + 8.0 * t[7]
+
+
+def run_variants(ctx, ix, text_d, batches, nq, L, counts, tally, oi, cores, ablate_lcx=False):
     """the same index, other batches (N = 1): no seed table, k-mers drawn from the text (default and LF-only), ASCII resident"""
     torch, dev, stream = ctx.torch, ctx.dev, ctx.stream
     from tests import synth
@@ -174,41 +202,70 @@ def run_variants(ctx, ix, text, batches, nq, L, counts, tally, oi, cores):
                          "note": "frac prices only the blocks ranked after a query's first 10 steps (+ query and result words): the <= 2 * 4^j lines "
                                  "of step j <= 10 are shared by all queries and stay in L2 / Infinity Cache; all steps priced at 104 B "
                                  "(algorithmic_GBs_all_steps) exceed what HBM can deliver"}
-    # queries drawn from the text: present => every letter has to be matched
-    ns = min(nq, 2_000_000)
-    present = synth.sampled_queries(text, ns, L, 77)
-    d_ascii = torch.from_numpy(present.reshape(-1)).to(dev)
-    d_words = torch.zeros(ns, dtype=torch.int64, device=dev)
+    # k-mers at uniform text positions (windows with an N skipped): present => every letter has to be matched.  PRESENT_BATCHES
+    # distinct batches, rotated
+    ns = nq
     d_bad = torch.zeros(1, dtype=torch.int64, device=dev)
-    ix.dev_pack_nt2(d_ascii.data_ptr(), ns, L, d_words.data_ptr(), d_bad.data_ptr(), stream, 0)
-    torch.cuda.synchronize()
+    pres, first_ascii = [], None
+    for j in range(PRESENT_BATCHES):
+        a = device_sampled_reads(torch, text_d, ns, L, 7700 + j, ord("N"))
+        w = torch.zeros(ns, dtype=torch.int64, device=dev)
+        ix.dev_pack_nt2(a.data_ptr(), ns, L, w.data_ptr(), d_bad.data_ptr(), stream, 0)
+        torch.cuda.synchronize()
+        if j == 0:
+            first_ascii = a[:min(ns, 1_000_000)].cpu().numpy()
+        pres.append(w)
+        del a
     assert int(d_bad.item()) == 0
-    ms = ctx.timed("present", lambda: ix.dev_count_nt2(d_words.data_ptr(), ns, L, counts.data_ptr(), True, stream, 0), 2, 5)
+    it = iter(range(1000))
+    ms = ctx.timed("present", lambda: ix.dev_count_nt2(pres[next(it) % PRESENT_BATCHES].data_ptr(), ns, L, counts.data_ptr(), True, stream, 0), PRESENT_BATCHES, 2 * PRESENT_BATCHES)
+    ix.dev_count_nt2(pres[0].data_ptr(), ns, L, counts.data_ptr(), True, stream, 0)
     assert bool((counts[:ns] >= 1).all()), "a k-mer sampled from the text was not found"
     want_present = counts[:ns].clone()
     tally.zero_()
-    ix.dev_count_nt2_tally(d_words.data_ptr(), ns, L, counts.data_ptr(), tally.data_ptr(), True, stream, 0)
+    ix.dev_count_nt2_tally(pres[0].data_ptr(), ns, L, counts.data_ptr(), tally.data_ptr(), True, stream, 0)
     torch.cuda.synchronize()
-    p3, s3, b3, v3, t3 = [int(x) for x in tally.cpu().tolist()[:5]]
-    ab = 16.0 * p3 + 104.0 * b3 + ns * 16.0 + 8.0 * v3 + 8.0 * t3
-    extra["present_queries"] = {"queries": ns, "queries_per_s": ns / (ms * 1e-3), "kernel_ms": ms,
+    tl = [int(x) for x in tally.cpu().tolist()]
+    p3, s3, b3, v3, t3 = tl[:5]
+    ab = 16.0 * p3 + 104.0 * b3 + ns * 16.0 + 8.0 * v3 + 8.0 * t3 + lcx_price(tl)
+    cp = want_present.cpu().numpy()
+    extra["present_queries"] = {"queries": ns, "batches_rotated": PRESENT_BATCHES, "queries_per_s": ns / (ms * 1e-3), "kernel_ms": ms,
                                 "achieved_GBs": ab / (ms * 1e-3) / 1e9, "frac": ab / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                 "steps_per_query": s3 / ns, "verify_sa_reads_per_query": v3 / ns, "verify_text_windows_per_query": t3 / ns,
-                                "random_lines_per_s": (p3 + b3 + v3 + t3) / (ms * 1e-3), "seed_and_verify": bool(ix.verify_enabled())}
+                                "lcx_nodes_per_query": tl[6] / ns, "lcx_entries_per_query": tl[7] / ns,
+                                "random_lines_per_s": (p3 + b3 + v3 + t3 + tl[6] + tl[7]) / (ms * 1e-3), "seed_and_verify": bool(ix.verify_enabled()),
+                                "left_context_index": bool(ix.lcx_enabled()),
+                                "mean_count": float(cp.mean()), "fraction_count_gt_1": float((cp > 1).mean()), "fraction_count_gt_8": float((cp > 8).mean()),
+                                "max_count": int(cp.max())}
     if oi is not None:  # the oracle on a sample of the same k-mers
-        nso = min(ns, 1_000_000)
-        ocounts, _ = oi.parallel_count(*synth.fixed_to_csr(present[:nso]), cores)
-        ok = bool(np.array_equal(ocounts, want_present[:nso].cpu().numpy().view(np.uint64)))
+        nso = len(first_ascii)
+        ocounts, _ = oi.parallel_count(*synth.fixed_to_csr(first_ascii), cores)
+        ok = bool(np.array_equal(ocounts, cp[:nso].view(np.uint64)))
         extra["present_queries"]["gpu_matches_oracle_on_sample"] = ok
         extra["present_queries"]["oracle_sample"] = nso
         assert ok, "GPU counts of k-mers from the text differ from the oracle"
-    # the same k-mers by LF steps only (seed-and-verify accelerators dropped): the contrast to the default
     had_verify = ix.verify_enabled()
+    if ablate_lcx and ix.lcx_enabled():  # round 2's schedule: seed-and-verify, no left-context index (LF steps until <= 8 rows)
+        ix.set_lcx(False)
+        it = iter(range(1000))
+        msx = ctx.timed("present_no_lcx", lambda: ix.dev_count_nt2(pres[next(it) % PRESENT_BATCHES].data_ptr(), ns, L, counts.data_ptr(), True, stream, 0), PRESENT_BATCHES, PRESENT_BATCHES)
+        ix.dev_count_nt2(pres[0].data_ptr(), ns, L, counts.data_ptr(), True, stream, 0)
+        assert bool(torch.equal(counts[:ns], want_present)), "the left-context index changed a count"
+        tally.zero_()
+        ix.dev_count_nt2_tally(pres[0].data_ptr(), ns, L, counts.data_ptr(), tally.data_ptr(), True, stream, 0)
+        torch.cuda.synchronize()
+        tx = [int(x) for x in tally.cpu().tolist()]
+        extra["present_queries_without_left_context_index"] = {"queries_per_s": ns / (msx * 1e-3), "kernel_ms": msx, "steps_per_query": tx[1] / ns,
+                                                               "block_reads_per_query": tx[2] / ns, "identical_counts": True}
+        ix.set_lcx(True)
+    # the same k-mers by LF steps only (seed-and-verify accelerators dropped): the contrast to the default
     ix.set_verify(-1)
-    msv = ctx.timed("present_lf", lambda: ix.dev_count_nt2(d_words.data_ptr(), ns, L, counts.data_ptr(), True, stream, 0), 2, 5)
+    it = iter(range(1000))
+    msv = ctx.timed("present_lf", lambda: ix.dev_count_nt2(pres[next(it) % PRESENT_BATCHES].data_ptr(), ns, L, counts.data_ptr(), True, stream, 0), 1, PRESENT_BATCHES)
+    ix.dev_count_nt2(pres[0].data_ptr(), ns, L, counts.data_ptr(), True, stream, 0)
     assert bool(torch.equal(counts[:ns], want_present)), "seed-and-verify changed a count"
     tally.zero_()
-    ix.dev_count_nt2_tally(d_words.data_ptr(), ns, L, counts.data_ptr(), tally.data_ptr(), True, stream, 0)
+    ix.dev_count_nt2_tally(pres[0].data_ptr(), ns, L, counts.data_ptr(), tally.data_ptr(), True, stream, 0)
     torch.cuda.synchronize()
     p4, s4, b4 = [int(x) for x in tally.cpu().tolist()[:3]]
     ab = 16.0 * p4 + 104.0 * b4 + ns * 16.0
@@ -217,9 +274,11 @@ def run_variants(ctx, ix, text, batches, nq, L, counts, tally, oi, cores):
                                               "identical_counts": True}
     if had_verify:
         ix.set_verify(2)
+    del pres
     if ctx.child:
         return extra
     # ASCII boundary with on-device packing in the timed region (31 B/query read instead of 8 B)
+    ix.dev_count_nt2(batches[0].data_ptr(), nq, L, counts.data_ptr(), True, stream, 0)
     na = min(nq, 5_000_000)
     asc = torch.from_numpy(unpack_nt2(batches[0][:na].cpu().numpy().view(np.uint64), L).reshape(-1)).to(dev)
     w2 = torch.zeros(na, dtype=torch.int64, device=dev)
@@ -237,41 +296,47 @@ def run_variants(ctx, ix, text, batches, nq, L, counts, tally, oi, cores):
     import awry_amd
     h_q = asc.cpu().numpy()
     h_off = np.arange(na + 1, dtype=np.uint64) * np.uint64(L)
+    want_h = counts[:na].cpu().numpy().view(np.uint64)
 
-    def host_median(fn, reps=8):
+    def host_times(fn, reps=8):
         ts = []
         for _ in range(reps):
             tp = time.perf_counter()
             fn()
             ts.append(time.perf_counter() - tp)
-        return sorted(ts[1:])[len(ts[1:]) // 2]
+        return ts
 
     h_counts = np.zeros(na, dtype=np.uint64)  # caller-owned counts_out, reused from call to call
-    med = host_median(lambda: ix.parallel_count_csr(h_q, h_off, h_counts))
-    assert np.array_equal(h_counts, counts[:na].cpu().numpy().view(np.uint64))
+    ts = host_times(lambda: ix.parallel_count_csr(h_q, h_off, h_counts))
+    first_call, med = ts[0], sorted(ts[1:])[len(ts[1:]) // 2]
+    assert np.array_equal(h_counts, want_h)
     kept = []  # results stay alive while the clock runs: releasing a 40 MB array (munmap) is the caller's cost, after the call
-    med_fresh = host_median(lambda: kept.append(ix.parallel_count_csr(h_q, h_off)))
+    ts = host_times(lambda: kept.append(ix.parallel_count_csr(h_q, h_off)))
+    med_fresh = sorted(ts[1:])[len(ts[1:]) // 2]
     tp = time.perf_counter()
     n_kept = len(kept)
     del kept
     release_ms = (time.perf_counter() - tp) / n_kept * 1e3
     h_words = batches[0][:na].cpu().numpy().view(np.uint64)
-    med_packed = host_median(lambda: ix.parallel_count_packed(h_words, L, h_counts))
-    assert np.array_equal(h_counts, counts[:na].cpu().numpy().view(np.uint64))
+    ts = host_times(lambda: ix.parallel_count_packed(h_words, L, h_counts))
+    med_packed = sorted(ts[1:])[len(ts[1:]) // 2]
+    assert np.array_equal(h_counts, want_h)
     extra["host_boundary_end_to_end"] = {
-        "queries": na, "queries_per_s": na / med, "ms": med * 1e3, "host_in_GBs": h_q.nbytes / med / 1e9,
+        "queries": na, "queries_per_s": na / med, "ms": med * 1e3, "first_call_ms": first_call * 1e3, "first_call_queries_per_s": na / first_call,
+        "host_in_GBs": h_q.nbytes / med / 1e9,
         "fresh_result_array_queries_per_s": na / med_fresh, "fresh_result_array_release_ms": release_ms,
         "caller_packed_kmers_queries_per_s": na / med_packed,
         "host_threads": awry_amd.load_library().awry_host_threads(),
-        "note": "awry_count_batch: ASCII + offsets in host memory -> counts in host memory, PCIe-inclusive, through the Python mirror, "
-                "median of 7 after 1 warm-up; the host packs 2 bits per letter on its worker pool (8 B per 31-mer over PCIe), "
+        "note": "awry_count_batch: ASCII + offsets in host memory -> counts in host memory, PCIe-inclusive, through the Python mirror; "
+                "first_call = the process's very first call (pinned lane staging is set up by awry_set_devices), queries_per_s = median of the 7 "
+                "calls after it; the host packs 2 bits per letter on its worker pool (8 B per 31-mer over PCIe), "
                 "counts return as 32-bit words; queries_per_s reuses the caller's result array, fresh_result_array allocates "
                 "one per call (mmap + first-touch page faults; the arrays are released after the clock stops: "
                 "fresh_result_array_release_ms each, the allocator's munmap -- a cost the caller of any API that returns a new array pays)"}
     return extra
 
 
-def locate_benchmark(ctx, ix, text, n_reads, read_len, oi=None, cores=1):
+def locate_benchmark(ctx, ix, text_d, n_reads, read_len, oi=None, cores=1):
     """SA-locate hits/s (BASELINE.json's second metric; configs[2]: 100 M 101-bp reads sampled from the text, exact match).
     Pipeline on the device: packed reads -> count (+range starts) -> scan -> tile locate (-> walk -> localise).  Timed per
     phase with HIP events, for the file's row samples (ratio 8: LF walks, tallied by the walk kernel), for the dense device
@@ -280,7 +345,6 @@ def locate_benchmark(ctx, ix, text, n_reads, read_len, oi=None, cores=1):
     from tests import synth
     ix.set_verify(-1)  # the default policy keeps the accelerators resident; measure the plain pipelines first
     ix.set_locate_sa_ratio(0)
-    text_d = torch.from_numpy(np.ascontiguousarray(text)).to(dev)
     d_reads = device_sampled_reads(torch, text_d, n_reads, read_len, 4242, ord("N"))
     W = (read_len + 31) // 32
     d_words = torch.zeros(n_reads * W, dtype=torch.int64, device=dev)
@@ -301,7 +365,9 @@ def locate_benchmark(ctx, ix, text, n_reads, read_len, oi=None, cores=1):
     assert bool((d_counts >= 1).all()), "a read sampled from the text was not found"
     d_g = torch.zeros(max(total, 1), dtype=torch.int64, device=dev)
     d_p = torch.zeros(2 * max(total, 1), dtype=torch.int64, device=dev)
-    out = {"reads": n_reads, "read_len": read_len, "hits": total, "count_phase_ms": ms_count, "scan_ms": ms_scan,
+    out = {"reads": n_reads, "read_len": read_len, "hits": total, "hits_per_read": total / n_reads,
+           "fraction_of_reads_with_more_than_one_hit": float((d_counts > 1).float().mean().item()), "max_hits_of_a_read": int(d_counts.max().item()),
+           "count_phase_ms": ms_count, "scan_ms": ms_scan,
            "count_phase_reads_per_s": n_reads / (ms_count * 1e-3), "seed_k": ix.seed_kmer_len()}
     ref = None
     for ratio in (0, 1):  # 0 = the file's samples (suffix_array_compression_ratio 8), 1 = dense device SA
@@ -352,7 +418,8 @@ def locate_benchmark(ctx, ix, text, n_reads, read_len, oi=None, cores=1):
                               "accelerator_build_s": build_s, "identical_locations": True}
     off_h = d_off[:nh_reads + 1].cpu().numpy().view(np.uint64)
     ref_h = ref[:int(off_h[-1])].cpu().numpy().view(np.uint64)
-    del text_d, d_reads, d_words, d_g, d_p, ref
+    out["seed_and_verify"]["left_context_index"] = bool(ix.lcx_enabled())
+    del d_reads, d_words, d_g, d_p, ref
     torch.cuda.empty_cache()
     if ctx.child:
         return out
@@ -371,10 +438,12 @@ def locate_benchmark(ctx, ix, text, n_reads, read_len, oi=None, cores=1):
     assert np.array_equal(hoff, off_h) and np.array_equal(hg, ref_h[:nhh]), "host-boundary locate differs from the device-resident pipeline"
     assert np.array_equal(hoff2, hoff) and np.array_equal(hg2, hg)
     dt, dtg = sorted(times[1:])[1], sorted(times_g[1:])[1]
-    out["host_boundary_end_to_end"] = {"reads": nh_reads, "hits": nhh, "ms": dt * 1e3, "reads_per_s": nh_reads / dt,
+    out["host_boundary_end_to_end"] = {"reads": nh_reads, "hits": nhh, "ms": dt * 1e3, "reads_per_s": nh_reads / dt, "hits_per_s": nhh / dt,
+                                       "first_call_ms": times[0] * 1e3, "first_call_reads_per_s": nh_reads / times[0],
                                        "positions_only_reads_per_s": nh_reads / dtg,
-                                       "note": "awry_locate_batch, PCIe-inclusive, through the Python mirror, median of 3 after 1 warm-up; reads packed on "
-                                               "the host; positions_only passes hits_out = NULL (8 B per hit back instead of 24)"}
+                                       "note": "awry_locate_batch, PCIe-inclusive, through the Python mirror: first_call = the process's first locate call "
+                                               "(the pinned result pool and lane staging are set up by awry_set_devices), reads_per_s = median of the 3 calls "
+                                               "after it; reads packed on the host; positions_only passes hits_out = NULL (8 B per hit back instead of 24)"}
     del hoff, hg, hoff2, hg2
     if oi is not None:
         ns = min(nh_reads, 200_000)
@@ -552,11 +621,12 @@ def pmc_child(args):
     torch.cuda.synchronize()
     ctx.end_phase()
     if not args.no_variants:
-        text = np.load(st["text"], mmap_mode="r")
-        run_variants(ctx, ix, text, batches, nq, L, counts, tally, None, 1)
+        text_d = torch.from_numpy(np.load(st["text"])).to(dev)
+        run_variants(ctx, ix, text_d, batches, nq, L, counts, tally, None, 1)
         del batches, counts
         torch.cuda.empty_cache()
-        locate_benchmark(ctx, ix, text, args.locate_reads, 101)
+        locate_benchmark(ctx, ix, text_d, args.locate_reads, 101)
+        del text_d
         if st.get("amino_index"):
             ix.close()
             torch.cuda.empty_cache()
@@ -567,22 +637,85 @@ def pmc_child(args):
     json.dump(ctx.phases, open(args.phase_file, "w"))
 
 
+def iid_comparison(ctx, args, torch, dev, local_rank, nq, L, n_text, n_reads):
+    """the same three device-resident legs on an i.i.d. text of the same size (a second index, built and dropped here): what
+    the rates of the repeat-rich default are to be read against"""
+    import awry_amd
+    from tests import synth
+    stream = ctx.stream
+    t0 = time.time()
+    text, starts, headers, _ = workload_text(args, torch, dev, "grch38", n_text)
+    ix = awry_amd.FmIndex.from_text(text, 0, 8, 0, starts, headers, build_device=local_rank).set_devices([local_rank])
+    text_d = torch.from_numpy(text).to(dev)
+    del text
+    out = {"text": "i.i.d. uniform ACGT, %d bp, 25 records, 5 %% N" % n_text, "seed_k": ix.seed_kmer_len(), "setup_s": time.time() - t0}
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(4321)
+    counts = torch.zeros(nq, dtype=torch.int64, device=dev)
+    d_bad = torch.zeros(1, dtype=torch.int64, device=dev)
+
+    def timed(fn, warm, reps):
+        for _ in range(warm):
+            fn()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(reps):
+            fn()
+        b.record()
+        torch.cuda.synchronize()
+        return a.elapsed_time(b) / reps
+
+    rb = [torch.randint(0, 1 << (2 * L), (nq,), dtype=torch.int64, device=dev, generator=gen) for _ in range(4)]
+    it = iter(range(1000))
+    out["random_queries_per_s"] = nq / (timed(lambda: ix.dev_count_nt2(rb[next(it) % 4].data_ptr(), nq, L, counts.data_ptr(), True, stream, 0), 2, 8) * 1e-3)
+    del rb
+    pb = []
+    for j in range(PRESENT_BATCHES):
+        a = device_sampled_reads(torch, text_d, nq, L, 7700 + j, ord("N"))
+        w = torch.zeros(nq, dtype=torch.int64, device=dev)
+        ix.dev_pack_nt2(a.data_ptr(), nq, L, w.data_ptr(), d_bad.data_ptr(), stream, 0)
+        torch.cuda.synchronize()
+        pb.append(w)
+        del a
+    it = iter(range(1000))
+    out["present_queries_per_s"] = nq / (timed(lambda: ix.dev_count_nt2(pb[next(it) % PRESENT_BATCHES].data_ptr(), nq, L, counts.data_ptr(), True, stream, 0), PRESENT_BATCHES, 2 * PRESENT_BATCHES) * 1e-3)
+    assert bool((counts >= 1).all())
+    del pb
+    RL, W = 101, 4
+    reads = device_sampled_reads(torch, text_d, n_reads, RL, 4242, ord("N"))
+    words = torch.zeros(n_reads * W, dtype=torch.int64, device=dev)
+    ix.dev_pack_nt2(reads.data_ptr(), n_reads, RL, words.data_ptr(), d_bad.data_ptr(), stream, 0)
+    del reads
+    rc = torch.zeros(n_reads, dtype=torch.int64, device=dev)
+    rs = torch.zeros(n_reads, dtype=torch.int64, device=dev)
+    out["reads_101_count_phase_reads_per_s"] = n_reads / (timed(lambda: ix.dev_count_nt2_long(words.data_ptr(), n_reads, RL, rc.data_ptr(), rs.data_ptr(), True, stream, 0), 1, 3) * 1e-3)
+    out["reads"] = n_reads
+    assert bool((rc >= 1).all())
+    ix.close()
+    del text_d, words, rc, rs, counts
+    torch.cuda.empty_cache()
+    return out
+
+
 # ------------------------------------------------------------------------------------------------ main
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default=os.environ.get("AWRY_BENCH_WORKLOAD", "grch38"), choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default=os.environ.get("AWRY_BENCH_WORKLOAD", "grch38-repeats"), choices=sorted(WORKLOADS))
     ap.add_argument("--text-len", type=int, default=0, help="override the workload's text length")
-    ap.add_argument("--queries", type=int, default=10_000_000, help="queries per GPU per step")
+    ap.add_argument("--queries", type=int, default=0, help="queries per GPU per step (default: 10 M at N = 1; at N > 1 the 10^9 queries of "
+                                                           "BASELINE configs[4] divided over the ranks and steps)")
     ap.add_argument("--qlen", type=int, default=31)
     ap.add_argument("--seed-k", type=int, default=-1, help="device seed-table k (-1 = library default, 0 = off)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline duration (0 = skip)")
     ap.add_argument("--no-variants", action="store_true")
     ap.add_argument("--locate-reads", type=int, default=100_000_000, help="101-bp reads in the locate measurement (N=1): BASELINE configs[2] has 100 M")
     ap.add_argument("--sweep-seed-k", default="", help="comma list of seed k to time on rank 0 before the run (stderr)")
-    ap.add_argument("--amino", action="store_true", help="run the amino leg (configs[3]) with any workload (default: with grch38)")
+    ap.add_argument("--amino", action="store_true", help="run the amino leg (configs[3]) with any workload (default: with the grch38 workloads)")
+    ap.add_argument("--no-iid", action="store_true", help="skip the i.i.d. comparison legs of the repeat-rich workload")
+    ap.add_argument("--ablate-lcx", action="store_true", help="also time the k-mers from the text with the left-context index switched off")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 counter passes (traffic falls back to profiles/traffic.json)")
     ap.add_argument("--pmc-timeout", type=int, default=300, help="seconds one counter pass may take")
     ap.add_argument("--keep-pmc", default="", help="directory that receives the counter CSVs of the live passes")
@@ -593,15 +726,23 @@ def main():
     if args.pmc_child:
         return pmc_child(args)
     if args.in_process:
+        if not args.queries:
+            args.queries = 10_000_000
         from tools import bench_in_process
         return bench_in_process.main(args)
-
-    import torch
-    import torch.distributed as dist
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    # one process per GPU shares the host with the other ranks: each rank's packer pool gets its share of the CPU quota
+    # (read once, when the library starts its pool)
+    if world > 1 and "AWRY_HOST_THREADS" not in os.environ:
+        os.environ["AWRY_HOST_THREADS"] = str(max(1, effective_cpus() // max(1, local_world)))
+
+    import torch
+    import torch.distributed as dist
+
     if world != args.gpus:
         log("warning: WORLD_SIZE %d != --gpus %d; using WORLD_SIZE" % (world, args.gpus))
     # AWRY_BENCH_BACKEND=gloo + fewer GPUs than ranks is a rehearsal mode for the N > 1 code path on a 1-GPU box
@@ -622,10 +763,14 @@ def main():
     import awry_amd
     from tests import synth
 
-    n_text, n_rec, n_frac = WORKLOADS[args.workload]
+    n_text, n_rec, n_frac, comp = WORKLOADS[args.workload]
     if args.text_len:
         n_text = args.text_len
-    L, nq, K, W = args.qlen, args.queries, args.steps, args.warmup
+    L, K, W = args.qlen, args.steps, args.warmup
+    # queries per GPU per step: 10 M at N = 1 (configs[1] / the headline); at N > 1 BASELINE configs[4]'s 10^9 queries in
+    # total, divided over the ranks and the K timed steps (N = 8, K = 20: 6.25 M per launch)
+    TOTAL_N = 1_000_000_000
+    nq = args.queries or (10_000_000 if world == 1 else max(1_000_000, -(-TOTAL_N // (world * K))))
     shm = "/tmp"  # scratch for the index / text handed to the other ranks and to the counter passes: RAM-backed when there is room
     try:
         st = os.statvfs("/dev/shm")
@@ -640,20 +785,21 @@ def main():
     # ---- index: built ONCE (rank 0, on its GPU) and handed to the other ranks as an .awry v1 file; every rank then
     #      replicates it into its own GPU's HBM and builds its seed table / accelerators there, concurrently
     t0 = time.time()
-    text = None
+    text, text_info = None, None
     if rank == 0:
-        text, starts, headers = synth.make_text(n_text, 0, 0xA5A50000 + 2, n_rec, n_frac)
+        text, starts, headers, text_info = workload_text(args, torch, dev, None, n_text)
+        torch.cuda.empty_cache()
         t1 = time.time()
         ix = awry_amd.FmIndex.from_text(text, 0, 8, 0, starts, headers, build_device=local_rank)
         t2 = time.time()
         index_path = os.path.join(tmpdir, "index.awry")
         if world > 1 or args.cpu_seconds > 0 or want_pmc:
             ix.save(index_path)  # .awry v1 in the reference's own layout: 160-B blocks, packed SA, k-mer table
-        log("text %.1fs, index build %.1fs, save %.1fs" % (t1 - t0, t2 - t1, time.time() - t2))
+        log("text %.1fs (%s), index build %.1fs, save %.1fs" % (t1 - t0, json.dumps(text_info), t2 - t1, time.time() - t2))
     if world > 1:
-        box = [index_path]
+        box = [index_path, text_info]
         dist.broadcast_object_list(box, src=0)
-        index_path = box[0]
+        index_path, text_info = box
         if rank != 0:
             ix = awry_amd.FmIndex.load(index_path)
     t2 = time.time()
@@ -662,12 +808,12 @@ def main():
         ix.set_seed_kmer_len(args.seed_k)
     t3 = time.time()
     if rank == 0:
-        log("replicate+seed(k=%d)+accelerators %.1fs, bwt_len=%d" % (ix.seed_kmer_len(), t3 - t2, ix.bwt_len()))
+        log("replicate+seed(k=%d)+accelerators(left-context index: %s) %.1fs, bwt_len=%d" % (ix.seed_kmer_len(), bool(ix.lcx_enabled()), t3 - t2, ix.bwt_len()))
     ctx = Ctx(torch, dev)
     ctx.ix = ix
     stream = ctx.stream
     # the committed counter passes (profiles/traffic.json) describe exactly this configuration and no other
-    default_config = args.workload == "grch38" and not args.text_len and nq == 10_000_000 and L == 31 and ix.seed_kmer_len() == 17
+    default_config = args.workload == "grch38-repeats" and not args.text_len and nq == 10_000_000 and L == 31 and ix.seed_kmer_len() == 17
 
     # ---- synthetic query batches, generated on the device: a uniform random L-mer is a uniform 2L-bit integer
     gen = torch.Generator(device=dev)
@@ -708,14 +854,25 @@ def main():
     elapsed = time.perf_counter() - t_start
     kernel_ms = ev0.elapsed_time(ev1) / K  # HIP events on the stream the kernel runs on
 
+    # ---- the same K steps once more, each bracketed by its own pair of events: the median beside the mean
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(K)]
+    for i, (a, b) in enumerate(evs):
+        a.record()
+        step(W + i)
+        b.record()
+    torch.cuda.synchronize()
+    per_step = sorted(a.elapsed_time(b) for a, b in evs)
+    kernel_ms_median = per_step[len(per_step) // 2]
+
     # ---- work census of the timed batches (same kernel, TALLY variant, untimed)
     for i in range(K):
         ix.dev_count_nt2_tally(batches[(W + i) % n_batches].data_ptr(), nq, L, counts.data_ptr(), tally.data_ptr(), True, stream, 0)
     torch.cuda.synchronize()
-    probes, steps_exec, blocks, vsa, vtxt = [int(x) / K for x in tally.cpu().tolist()[:5]]
+    tl = [int(x) / K for x in tally.cpu().tolist()]
+    probes, steps_exec, blocks, vsa, vtxt = tl[:5]
     # probe 16 B, block 104 B, query 8 B, result 8 B; seed-and-verify (survivors only): 8 B per SA read
-    # and the <= 8 B text window of the remaining letters
-    alg_bytes = 16.0 * probes + 104.0 * blocks + nq * (8.0 + 8.0) + 8.0 * vsa + 8.0 * vtxt
+    # and the <= 8 B text window of the remaining letters; left-context index: 32 B per node consulted, 8 B per entry read
+    alg_bytes = 16.0 * probes + 104.0 * blocks + nq * (8.0 + 8.0) + 8.0 * vsa + 8.0 * vtxt + lcx_price(tl)
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
     if world > 1:
@@ -724,37 +881,44 @@ def main():
     total_q = float(nq) * K * world
     value = total_q / elapsed_max
 
+    tdesc = "%s-scale synthetic nucleotide text (%d bp, %d record(s), %.0f%% N, %s, %.0f%% of it in repeats)" % (
+        args.workload.split("-")[0], n_text, n_rec, 100 * text_info.get("n_fraction", n_frac), text_info["composition"], 100 * text_info.get("repeat_fraction", 0.0))
     result = {
         "metric": "k-mer count queries/sec (parallel_count, random %d-mers, index resident in HBM)" % L,
         "value": value, "unit": "queries/s", "n_gpus": world, "steps": K, "warmup": W,
-        "ms_per_step": 1000.0 * elapsed_max / K, "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": 1000.0 * elapsed_max / K, "higher_is_better": True, "scaling": "weak" if world == 1 or args.queries else "strong",
         "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-        "config": {"workload": "%s-scale synthetic nucleotide text (%d bp, %d record(s), %.0f%% N), %d uniform-random %d-mers per GPU per step, "
-                               "packed 2-bit queries resident in HBM, seed table k=%d, SA ratio 8"
-                               % (args.workload, n_text, n_rec, 100 * n_frac, nq, L, ix.seed_kmer_len()),
-                   "text_len": n_text, "queries_per_gpu_per_step": nq, "query_len": L, "seed_k": ix.seed_kmer_len(),
-                   "sharding": "index replicated per GPU (built once, handed over as .awry v1), queries sharded by rank, no collective"},
+        "config": {"workload": tdesc + ", %d uniform-random %d-mers per GPU per step%s, packed 2-bit queries resident in HBM, seed table k=%d, SA ratio 8"
+                               % (nq, L, "" if world == 1 or args.queries else " = BASELINE configs[4]'s 10^9 queries in all over %d GPUs x %d steps" % (world, K),
+                                  ix.seed_kmer_len()),
+                   "text_len": n_text, "text": text_info, "queries_per_gpu_per_step": nq, "total_queries_timed": int(total_q), "query_len": L,
+                   "seed_k": ix.seed_kmer_len(), "left_context_index": bool(ix.lcx_enabled()),
+                   "sharding": "index replicated per GPU (built once, handed over as .awry v1), queries sharded by rank, no collective",
+                   "ranks": world, "backend": ("rccl (torch.distributed nccl)" if backend == "nccl" else backend) if world > 1 else None},
         "roofline": {"bound": "hbm", "kernel": ix.count_schedule(L), "achieved": alg_bytes / (kernel_ms * 1e-3) / 1e9,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg_bytes / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                     "traffic": None, "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": alg_bytes,
+                     "traffic": None, "kernel_ms": kernel_ms, "kernel_ms_median_of_%d" % K: kernel_ms_median,
+                     "queries_per_s_at_median": nq / (kernel_ms_median * 1e-3), "algorithmic_bytes_per_launch": alg_bytes,
+                     # the device's seed entry is 8 bytes, SURVEY 8(d) prices a probe at 16: the same fraction on the bytes actually needed
+                     "frac_at_8_byte_probe": (alg_bytes - 8.0 * probes) / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                      "census_per_launch": {"seed_probes": probes, "steps": steps_exec, "block_reads": blocks,
-                                           "verify_sa_reads": vsa, "verify_text_windows": vtxt}},
+                                           "verify_sa_reads": vsa, "verify_text_windows": vtxt, "lcx_nodes": tl[6], "lcx_entries": tl[7]}},
     }
     # the ceiling that actually binds this access pattern: random 128-B line requests (profiles/r01_gather_calibration.txt)
-    lines = probes + blocks + vsa + vtxt + nq * (8.0 + 8.0) / 128.0
+    lines = probes + blocks + vsa + vtxt + tl[6] + tl[7] + nq * (8.0 + 8.0) / 128.0
     result["roofline"]["random_line_rate"] = {"achieved_Glines_s": lines / (kernel_ms * 1e-3) / 1e9, "measured_ceiling_Glines_s": 48.0,
                                               "note": "seed probe + ranked blocks + verify SA reads and text windows + coalesced share of query/result words; ceiling = "
                                                       "tools/calib_gather.hip: 8-B probes into a 34-137 GiB table (53 on 2 GiB; 44 when whole 128-B lines are consumed)"}
 
     if rank == 0:
-        # nominal peak next to a measured streaming figure (device-to-device copy, read + write bytes)
+        # nominal peak next to a measured streaming figure: a HIP copy kernel, 16 B per lane per step, read + write bytes
         a = torch.empty(1 << 30, dtype=torch.uint8, device=dev)
         b = torch.empty_like(a)
-        b.copy_(a)
+        ix.dev_stream_copy(b.data_ptr(), a.data_ptr(), a.numel(), stream, 0)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(10):
-            b.copy_(a)
+            ix.dev_stream_copy(b.data_ptr(), a.data_ptr(), a.numel(), stream, 0)
         e1.record()
         torch.cuda.synchronize()
         result["roofline"]["peak_measured_stream_copy"] = 10 * 2 * a.numel() / (e0.elapsed_time(e1) * 1e-3) / 1e9
@@ -799,16 +963,28 @@ def main():
                 sys.exit(3)
         state = {"index": index_path, "seed_k": ix.seed_kmer_len()}
         if not args.no_variants:
-            result["variants"] = run_variants(ctx, ix, text, batches, nq, L, counts, tally, oi, cores)
+            text_d = torch.from_numpy(text).to(dev)
+            if want_pmc:
+                state["text"] = os.path.join(tmpdir, "text.npy")
+                np.save(state["text"], text)
+            del text
+            result["variants"] = run_variants(ctx, ix, text_d, batches, nq, L, counts, tally, oi, cores, args.ablate_lcx)
             del batches, counts
             torch.cuda.empty_cache()
-            result["locate"] = locate_benchmark(ctx, ix, text, args.locate_reads, 101, oi, cores)
+            result["locate"] = locate_benchmark(ctx, ix, text_d, args.locate_reads, 101, oi, cores)
+            del text_d
             if oi is not None:
                 oi.close()
                 oi = None
             ix.close()
             torch.cuda.empty_cache()
-            if args.workload == "grch38" or args.amino:
+            if comp == "repeats" and not args.no_iid:
+                result["iid_comparison"] = iid_comparison(ctx, args, torch, dev, local_rank, nq, L, n_text, min(args.locate_reads, 20_000_000))
+                lo, vq, ii = result["locate"]["seed_and_verify"], result["variants"]["present_queries"], result["iid_comparison"]
+                ii["ratio_iid_over_this_text"] = {"random_31mers": ii["random_queries_per_s"] / (nq / (kernel_ms * 1e-3)),
+                                                  "present_31mers": ii["present_queries_per_s"] / vq["queries_per_s"],
+                                                  "reads_101_count_phase": ii["reads_101_count_phase_reads_per_s"] / lo["count_phase_reads_per_s"]}
+            if args.workload.startswith("grch38") or args.amino:
                 atext, ast, ahd = synth.make_text(AMINO_TEXT, 1, 0xA5A50004, AMINO_RECORDS, 0.0)
                 ax = awry_amd.FmIndex.from_text(atext, 1, 8, 0, ast, ahd, build_device=local_rank)
                 aoi = None
@@ -829,6 +1005,15 @@ def main():
                     state["amino_text"] = os.path.join(tmpdir, "amino_text.npy")
                     np.save(state["amino_text"], atext)
                 del atext
+            # BASELINE's second metric and the drop-in boundary as top-level scalars of the line
+            lo = result["locate"]
+            result["locate_hits_per_s"] = lo["seed_and_verify"]["hits_per_s"]
+            result["locate_reads_per_s_end_to_end"] = lo["seed_and_verify"]["end_to_end_reads_per_s_device_resident"]
+            result["locate_hits_per_s_walks_to_file_samples"] = lo["sa_ratio_8"]["hits_per_s"]
+            result["present_queries_per_s"] = result["variants"]["present_queries"]["queries_per_s"]
+            result["host_boundary_count_queries_per_s"] = result["variants"]["host_boundary_end_to_end"]["queries_per_s"]
+            result["host_boundary_locate_reads_per_s"] = lo["host_boundary_end_to_end"]["reads_per_s"]
+            result["host_boundary_locate_hits_per_s"] = lo["host_boundary_end_to_end"]["hits_per_s"]
         else:
             del batches, counts
             ix.close()
@@ -837,10 +1022,12 @@ def main():
         #      it has released its HBM); falls back to the committed passes of the same phases
         pmc = {}
         if want_pmc:
-            state["text"] = os.path.join(tmpdir, "text.npy")
-            np.save(state["text"], text)
+            if "text" not in state:
+                state["text"] = os.path.join(tmpdir, "text.npy")
+                np.save(state["text"], text)
             state_path = os.path.join(tmpdir, "state.json")
             json.dump(state, open(state_path, "w"))
+            args.queries = nq
             tp = time.time()
             pmc = collect_pmc(args, state_path, tmpdir)
             log("counter passes: %.0f s, phases with traffic: %s" % (time.time() - tp, sorted(pmc)))
@@ -870,10 +1057,10 @@ def main():
     if world > 1:
         # parity re-checked at every G, outside the timed region.  All ranks count one common batch (half
         # k-mers of the text, half random; made by rank 0, which holds the text, and broadcast) twice: with the default
-        # schedule (seed table, context and position seeds, text comparison) and by plain backward search from the last
-        # letter with no table and no accelerator -- the reference's own algorithm on the GPU.  The two must agree on every
-        # rank, k-mers of the text must be found, and the replicas must agree among themselves (checksums reduced with
-        # MIN / MAX).  The oracle itself is compared against at N = 1 only (cpu_baseline).
+        # schedule (seed table, context and position seeds, left-context index, text comparison) and by plain backward search
+        # from the last letter with no table and no accelerator -- the reference's own algorithm on the GPU.  The two must
+        # agree on every rank, k-mers of the text must be found, the replicas must agree among themselves (checksums reduced
+        # with MIN / MAX), and rank 0 -- it holds the .awry file -- counts the same batch with the ORACLE.
         npar = 1_000_000
         if rank == 0:
             common = np.concatenate([synth.sampled_queries(text, npar // 2, L, 4711), synth.random_queries(npar // 2, L, 0, 4712)])
@@ -895,6 +1082,16 @@ def main():
         ix.dev_count_nt2(d_w.data_ptr(), npar, L, d_c2.data_ptr(), False, stream, 0)
         torch.cuda.synchronize()
         local_ok = bool(torch.equal(d_c, d_c2)) and bool((d_c[:npar // 2] >= 1).all()) and int(d_b.item()) == 0
+        oracle_ok, oracle_s = None, None
+        if rank == 0 and args.cpu_seconds > 0:
+            from oracle import oracle_ffi
+            tp = time.time()
+            oi = oracle_ffi.OracleIndex.load(index_path)
+            ocounts, _ = oi.parallel_count(*synth.fixed_to_csr(common), max(1, effective_cpus() // max(1, local_world)))
+            oi.close()
+            oracle_ok = bool(np.array_equal(ocounts, d_c.cpu().numpy().view(np.uint64)))
+            oracle_s = time.time() - tp
+            local_ok = local_ok and oracle_ok
         weights = torch.arange(1, npar + 1, dtype=torch.int64, device=dev) % 1000003
         chk = torch.stack([d_c.sum(), (d_c * weights).sum(), torch.tensor(1 if local_ok else 0, dtype=torch.int64, device=dev)])
         if backend != "nccl":
@@ -904,10 +1101,34 @@ def main():
         dist.all_reduce(hi_, op=dist.ReduceOp.MAX)
         agree = bool(torch.equal(lo_[:2], hi_[:2]))
         all_ok = int(lo_[2].item()) == 1
+        # ---- the drop-in boundary at N ranks: every rank pushes its own shard of ASCII 31-mers through awry_count_batch at
+        #      the same time (barrier before, max over ranks after); each rank's packer pool has 1/N of the CPU quota
+        nh = min(nq, 5_000_000)
+        h_q = unpack_nt2(batches[0][:nh].cpu().numpy().view(np.uint64), L).reshape(-1)
+        h_off = np.arange(nh + 1, dtype=np.uint64) * np.uint64(L)
+        h_counts = np.zeros(nh, dtype=np.uint64)
+        ix.parallel_count_csr(h_q, h_off, h_counts)  # first call
+        reps = 5
+        barrier()
+        tp = time.perf_counter()
+        for _ in range(reps):
+            ix.parallel_count_csr(h_q, h_off, h_counts)
+        th = torch.tensor([time.perf_counter() - tp], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(th, op=dist.ReduceOp.MAX)
+        ix.dev_count_nt2(batches[0].data_ptr(), nq, L, counts.data_ptr(), True, stream, 0)
+        torch.cuda.synchronize()
+        host_ok = bool(np.array_equal(h_counts, counts[:nh].cpu().numpy().view(np.uint64)))
         if rank == 0:
             result["parity_check"] = {"queries": npar, "present_fraction": 0.5, "replicas_agree": agree,
-                                      "default_schedule_equals_plain_backward_search_on_every_rank": all_ok}
-            if not (agree and all_ok):
+                                      "default_schedule_equals_plain_backward_search_on_every_rank": all_ok,
+                                      "rank0_gpu_matches_oracle_on_the_common_batch": oracle_ok, "oracle_s": oracle_s}
+            result["host_boundary_count_queries_per_s"] = float(nh) * reps * world / float(th.item())
+            result["host_boundary"] = {"queries_per_rank_per_call": nh, "calls": reps, "aggregate_queries_per_s": result["host_boundary_count_queries_per_s"],
+                                       "host_threads_per_rank": awry_amd.load_library().awry_host_threads(), "rank0_counts_equal_device_resident": host_ok,
+                                       "note": "awry_count_batch on every rank at once (ASCII in host memory -> counts in host memory, PCIe-inclusive); "
+                                               "the ranks share the host's CPU quota, AWRY_HOST_THREADS = quota / ranks each"}
+            result["device_resident_queries_per_s"] = value
+            if not (agree and all_ok and host_ok):
                 log("PARITY FAILURE at %d GPUs" % world)
                 print(json.dumps(result), flush=True)
                 dist.destroy_process_group()

@@ -118,6 +118,19 @@ int awry_locate_sa_ratio(const awry_index_t *idx);
 int awry_set_verify(awry_index_t *idx, int after_steps);
 int awry_set_verify_kmers(awry_index_t *idx, int on);
 int awry_verify_enabled(const awry_index_t *idx);
+/* left-context index (performance knob only; counts and locations do not depend on it): with the seed-and-verify accelerators
+ * resident, every seed bucket of 2+ rows keeps the 32 letters in FRONT of each of its suffixes, sorted, plus each suffix's text
+ * position and BWT row (16.6 B per row of the index: 51 GB for GRCh38).  The letters a query has left of its seed window are
+ * then matched by a 16-ary search over its bucket -- log16(rows) random lines -- instead of one LF step (two lines) per letter:
+ * what makes k-mers and reads from repeat families (10^3..10^5 rows per seed, dozens of letters before the rows part) cost a
+ * few lines like any other query.  Default policy (awry_set_devices): built when it and its build scratch fit 3/4 of the HBM
+ * still free once everything else is resident; env AWRY_LCX=0 / on = 0 switch it off (rebuilds the seed table), on = 1
+ * restores the policy.  awry_lcx_enabled: is it resident on replica 0. */
+int awry_set_lcx(awry_index_t *idx, int on);
+int awry_lcx_enabled(const awry_index_t *idx);
+/* device pointers of replica `slot`'s left-context index for tests that dump it: keys[bwt_len] (u64) and
+ * rowpos[bwt_len] (u64: text position | BWT row << 32); NULL when it is not resident */
+int awry_debug_lcx(const awry_index_t *idx, int slot, const void **d_keys, const void **d_rowpos);
 int awry_num_devices(const awry_index_t *idx);
 
 /* ---- batch queries --------------------------------------------------------------------------------- */
@@ -206,7 +219,8 @@ int awry_dev_count_nt2(awry_index_t *idx, int slot, const void *d_words, uint64_
                        int use_seed, void *stream);
 /* same kernel with a work census for the roofline figure: d_tally[6] (u64, caller-zeroed) += {seed probes,
  * executed steps, distinct BWT blocks ranked, SA reads and text windows of seed-and-verify, blocks ranked by steps
- * after a query's first 10 (single-kernel schedule only: the ones whose lines no longer sit in the Infinity Cache)} --
+ * after a query's first 10 (single-kernel schedule only: the ones whose lines no longer sit in the Infinity Cache), and --
+ * caller passes d_tally[8] -- nodes of the left-context index consulted, its (position, row) entries read} --
  * the first three are the tallies SURVEY.md 8(d) prices at 16 B / 104 B each */
 int awry_dev_count_nt2_tally(awry_index_t *idx, int slot, const void *d_words, uint64_t n, int L, void *d_counts,
                              int use_seed, void *d_tally, void *stream);
@@ -259,6 +273,9 @@ int awry_dev_memcpy_h2d(awry_index_t *idx, int slot, void *d_dst, const void *h_
 int awry_dev_memcpy_d2h(awry_index_t *idx, int slot, void *h_dst, const void *d_src, uint64_t bytes);
 int awry_dev_memset(awry_index_t *idx, int slot, void *d_dst, int value, uint64_t bytes);
 int awry_dev_synchronize(awry_index_t *idx, int slot);
+/* measurement aid: copies `bytes` (multiple of 16) from d_src to d_dst with 16-byte loads and stores per lane on `stream` --
+ * the streaming rate printed next to the nominal HBM peak */
+int awry_dev_stream_copy(awry_index_t *idx, int slot, void *d_dst, const void *d_src, uint64_t bytes, void *stream);
 /* time a region on `stream` with HIP events: begin/end record, elapsed synchronises and returns ms */
 int awry_dev_timer_begin(awry_index_t *idx, int slot, void *stream);
 int awry_dev_timer_end(awry_index_t *idx, int slot, void *stream, float *ms_out);

@@ -30,12 +30,35 @@ def test_in_process_replicas_mode():
 
 
 def test_one_process_per_gpu_mode_rehearsed_with_gloo():
+    """the N > 1 line as the driver will launch it (no --queries): BASELINE configs[4]'s 10^9 queries in all, divided over the
+    ranks and the timed steps; parity against the ORACLE on rank 0 besides the GPU-vs-GPU checks; device-resident and
+    host-boundary aggregates; each rank's packer pool sized to its share of the CPU quota"""
     env = dict(os.environ, AWRY_BENCH_BACKEND="gloo", AWRY_SEED_K="11", MASTER_ADDR="127.0.0.1")
+    env.pop("AWRY_HOST_THREADS", None)
     p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                        "--master-port", "29631", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "ecoli", "--queries", "500000",
-                        "--steps", "3", "--warmup", "1"], cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+                        "--master-port", "29631", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "ecoli",
+                        "--steps", "5", "--warmup", "1"], cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
     assert p.returncode == 0, p.stderr.decode()[-3000:]
     r = _json_line(p.stdout)
-    assert r["n_gpus"] == 2 and r["scaling"] == "weak" and r["value"] > 0
-    assert r["parity_check"]["replicas_agree"] and r["parity_check"]["default_schedule_equals_plain_backward_search_on_every_rank"]
-    assert "built once" in r["config"]["sharding"]
+    assert r["n_gpus"] == 2 and r["scaling"] == "strong" and r["value"] > 0
+    cfg = r["config"]
+    assert cfg["queries_per_gpu_per_step"] == 100_000_000 and cfg["total_queries_timed"] == 1_000_000_000 and "10^9" in cfg["workload"]
+    assert cfg["ranks"] == 2 and cfg["backend"] == "gloo"
+    pc = r["parity_check"]
+    assert pc["replicas_agree"] and pc["default_schedule_equals_plain_backward_search_on_every_rank"]
+    assert pc["rank0_gpu_matches_oracle_on_the_common_batch"] is True and pc["queries"] == 1_000_000
+    hb = r["host_boundary"]
+    assert hb["aggregate_queries_per_s"] > 0 and hb["rank0_counts_equal_device_resident"] and r["host_boundary_count_queries_per_s"] == hb["aggregate_queries_per_s"]
+    assert hb["host_threads_per_rank"] >= 1 and r["device_resident_queries_per_s"] == r["value"]
+    assert "built once" in cfg["sharding"]
+
+
+def test_explicit_batch_size_keeps_weak_scaling_label():
+    env = dict(os.environ, AWRY_BENCH_BACKEND="gloo", AWRY_SEED_K="11", MASTER_ADDR="127.0.0.1")
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29633", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "ecoli", "--queries", "500000",
+                        "--steps", "3", "--warmup", "1", "--cpu-seconds", "0"], cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    r = _json_line(p.stdout)
+    assert r["n_gpus"] == 2 and r["scaling"] == "weak" and r["config"]["queries_per_gpu_per_step"] == 500_000
+    assert r["parity_check"]["rank0_gpu_matches_oracle_on_the_common_batch"] is None  # --cpu-seconds 0: no oracle in the run

@@ -340,3 +340,44 @@ def test_save_without_a_device_is_byte_identical_to_reference_format(oracle, tmp
     assert open(a, "rb").read() == open(b, "rb").read()
     with pytest.raises(ValueError):
         FmIndex.from_text(text, alphabet, 6, kmer_len, st, hd[:-1])
+
+
+def test_host_pool_serves_concurrent_callers():
+    """the worker pool takes jobs from several threads at once (one per replica of a batch call over N replicas): eight
+    threads pack different batches concurrently, each many times, and every result equals the serial one"""
+    import threading
+    lib = awry_amd.load_library()
+    u64p, u32p = C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)
+    rng = np.random.default_rng(8)
+    L, n = 31, 300_000  # large enough for the packer to cut the batch over the pool
+    batches = [np.ascontiguousarray(synth.NT[rng.integers(0, 4, size=(n, L))]) for _ in range(8)]
+    for b in batches[::2]:
+        b[rng.integers(0, n, 50), rng.integers(0, L, 50)] = ord("N")
+
+    def pack(q):
+        words, bad, nb = np.zeros((n, 1), np.uint64), np.zeros(n, np.uint32), C.c_uint64()
+        assert lib.awry_host_pack_nt2(q.ctypes.data, None, n, L, words.ctypes.data_as(u64p), None, bad.ctypes.data_as(u32p), C.byref(nb)) == 0
+        good = np.ones(n, bool)
+        good[bad[:nb.value]] = False
+        return words[good].copy(), np.sort(bad[:nb.value]).copy()
+
+    want = [pack(q) for q in batches]
+    errors = []
+
+    def hammer(i):
+        try:
+            for _ in range(12):
+                w, b = pack(batches[i])
+                assert np.array_equal(w, want[i][0]) and np.array_equal(b, want[i][1])
+                dst = np.empty_like(batches[i])
+                lib.awry_host_memcpy(dst.ctypes.data, batches[i].ctypes.data, dst.nbytes)
+                assert np.array_equal(dst, batches[i])
+        except Exception as e:  # noqa: BLE001
+            errors.append((i, repr(e)))
+
+    th = [threading.Thread(target=hammer, args=(i,)) for i in range(8)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=300)
+    assert not errors and not any(t.is_alive() for t in th), errors

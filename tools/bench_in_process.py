@@ -29,7 +29,7 @@ def log(*a):
 def main(args):
     import torch
     import awry_amd
-    from bench import WORKLOADS, unpack_nt2
+    from bench import WORKLOADS, unpack_nt2, workload_text
     from tests import synth
 
     N = args.in_process
@@ -37,12 +37,10 @@ def main(args):
     if ndev < 1:
         raise SystemExit("no GPU visible")
     ids = [i % ndev for i in range(N)]
-    n_text, n_rec, n_frac = WORKLOADS[args.workload]
-    if args.text_len:
-        n_text = args.text_len
+    n_text = args.text_len or WORKLOADS[args.workload][0]
     L, nq, K, W = args.qlen, args.queries, args.steps, args.warmup
     t0 = time.time()
-    text, starts, headers = synth.make_text(n_text, 0, 0xA5A50000 + 2, n_rec, n_frac)
+    text, starts, headers, _ = workload_text(args, torch, torch.device("cuda", 0), None, n_text)
     ix = awry_amd.FmIndex.from_text(text, 0, 8, 0, starts, headers, build_device=0)
     t1 = time.time()
     ix.set_devices(ids)

@@ -14,6 +14,14 @@ n = int(float(sys.argv[1])) if len(sys.argv) > 1 else 3_100_000_000
 nk = int(float(sys.argv[2])) if len(sys.argv) > 2 else 10_000_000
 nr = int(float(sys.argv[3])) if len(sys.argv) > 3 else 20_000_000
 which = sys.argv[4] if len(sys.argv) > 4 else "both"
+if len(sys.argv) > 5:  # repeat families to leave out (an experiment: what do the young, high-copy families cost?)
+    drop = set(sys.argv[5].split(","))
+    synth.REPEAT_FAMILIES = tuple(f for f in synth.REPEAT_FAMILIES if f[0] not in drop)
+    if "satellite" in drop:
+        synth.SATELLITE_FRACTION = 0.0
+    if "segdup" in drop:
+        synth.SEGDUP_FRACTION = 0.0
+    print("left out:", sorted(drop), flush=True)
 dev = torch.device("cuda", 0)
 stream = torch.cuda.current_stream().cuda_stream
 
@@ -67,7 +75,9 @@ def run(kind):
         torch.cuda.synchronize()
         p, s, b, v, tx = [int(x) for x in tally.cpu().tolist()[:5]]
         c = counts.cpu().numpy()
+        tl = tally.cpu().tolist()
         out[name] = {"G_per_s": nk / ms / 1e6, "ms": ms, "steps_per_query": s / nk, "blocks_per_query": b / nk, "sa_reads_per_query": v / nk,
+                     "lcx_nodes_per_query": int(tl[6]) / nk, "lcx_entries_per_query": int(tl[7]) / nk,
                      "text_windows_per_query": tx / nk, "mean_count": float(c.mean()), "frac_count_gt1": float((c > 1).mean()),
                      "frac_count_gt8": float((c > 8).mean()), "max_count": int(c.max())}
         print(name, json.dumps(out[name]), flush=True)

@@ -206,6 +206,10 @@ struct Replica {
     DevBuf<uint64_t> w, range;
     DevBuf<uint32_t> q, count;
     uint64_t cap = 0, cap_q = 0;
+    // what lcx_lane_kernel leaves for the quad code: a second set of block-private lists with the same geometry
+    DevBuf<uint64_t> fw, frange;
+    DevBuf<uint32_t> fq, fcount;
+    uint64_t fcap = 0;
     // awry_dev_count_ascii_uniform on a nucleotide index: packed words of the batch, the pack kernel's list of queries with
     // other letters and its counter
     DevBuf<uint64_t> u_words;
@@ -961,6 +965,47 @@ Replica::SurvScratch* surv_scratch(Replica& r, hipStream_t s) {
   return slot.get();
 }
 
+// phase 2 with one survivor per lane (lcx_lane_kernel) whenever the left-context index is resident; AWRY_LCX_LANES=0 keeps the
+// quad kernels (which search the index four lanes per query) for A/B
+bool lcx_lanes(const Replica& r) {
+  static const bool off = getenv("AWRY_LCX_LANES") && !strcmp(getenv("AWRY_LCX_LANES"), "0");
+  return !off && r.dev.lcx_key != nullptr && r.dev.text4 != nullptr && r.dev.dense_ratio == 1;
+}
+// the survivor lists of a two-phase launch over n queries: `in` (all three arrays) and, with lanes, the fallback lists `out`
+void two_phase_lists(Replica& r, hipStream_t s, uint64_t n, bool lanes, Nt2Survivors* in, Nt2Survivors* out, unsigned* nblk_out) {
+  Replica::SurvScratch* sc = surv_scratch(r, s);
+  const unsigned nblk = (unsigned)r.num_cus * 8;  // lists = blocks of the probe pass
+  const uint64_t per_block = ((n + (uint64_t)nblk * 256 - 1) / ((uint64_t)nblk * 256)) * 256, total = per_block * nblk;
+  if (sc->cap < total || (lanes && sc->fcap < total)) {
+    HIP_CHECK(hipStreamSynchronize(s));
+    if (sc->cap < total) {
+      sc->w.alloc(total); sc->range.alloc(total); sc->q.alloc(total);
+      sc->cap = sc->cap_q = total;
+    }
+    if (lanes && sc->fcap < total) {
+      sc->fw.alloc(total); sc->frange.alloc(total); sc->fq.alloc(total);
+      sc->fcap = total;
+    }
+  }
+  if (!sc->count.p) sc->count.alloc(nblk);
+  if (lanes && !sc->fcount.p) sc->fcount.alloc(8);  // [0] length of the LF list, [2..3] the lane pass's batch counter
+  *in = Nt2Survivors{sc->w.p, sc->range.p, sc->q.p, sc->count.p, per_block};
+  *out = Nt2Survivors{};
+  if (lanes) {
+    *out = Nt2Survivors{sc->fw.p, sc->frange.p, sc->fq.p, sc->fcount.p, total};
+    in->pool_ctr = reinterpret_cast<unsigned long long*>(sc->fcount.p + 2);
+    in->lf_count = sc->fcount.p;
+  }
+  *nblk_out = nblk;
+}
+// blocks of lcx_lane_kernel that are resident at once (its 52 KB of LDS and ~150 VGPRs allow three per CU): the grid
+template <class K>
+unsigned resident_grid(const Replica& r, K kernel) {
+  int per_cu = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, 0) != hipSuccess || per_cu < 1) { (void)hipGetLastError(); per_cu = 2; }
+  return (unsigned)r.num_cus * (unsigned)per_cu;
+}
+
 // d_lens != nullptr: read q has d_lens[q] letters (1..L) in its W = ceil(L / 32) words; else every read has L letters
 void launch_count_nt2_long(Replica& r, const uint64_t* d_words, uint64_t n, int L, uint64_t* d_counts, uint64_t* d_range_start,
                            bool use_seed, hipStream_t s, const uint32_t* d_lens = nullptr) {
@@ -984,23 +1029,26 @@ void launch_count_nt2_long(Replica& r, const uint64_t* d_words, uint64_t n, int 
   if (vfy && sd && L - r.seed_k >= 3 && L <= 512 && n < (1ull << 32) && (om < 0 || om == 3)) {
     // two-phase: a per-lane pass settles the reads their seed entry (plus one SA read and one text window) decides,
     // the quad kernel works through the rest
-    Replica::SurvScratch* sc = surv_scratch(r, s);
-    const unsigned nblk = (unsigned)r.num_cus * 8;  // both phases use this grid
-    const uint64_t per_block = ((n + (uint64_t)nblk * 256 - 1) / ((uint64_t)nblk * 256)) * 256;  // reads a block sees
-    if (sc->cap_q < per_block * nblk) {
-      HIP_CHECK(hipStreamSynchronize(s));
-      sc->q.alloc(per_block * nblk);
-      sc->cap_q = per_block * nblk;
-      sc->cap = 0;  // the k-mer path re-allocates its three lists together
-    }
-    if (!sc->count.p) sc->count.alloc(nblk);
-    const Nt2Survivors sv{nullptr, nullptr, sc->q.p, sc->count.p, per_block};
+    const bool lanes = lcx_lanes(r);
+    Nt2Survivors sv, fb;
+    unsigned nblk = 0;  // both phases of the quad schedule use this grid
+    two_phase_lists(r, s, n, lanes, &sv, &fb, &nblk);
+    if (!lanes) sv.w = sv.range = nullptr;  // (the probe pass then lists the reads only)
+    const dim3 gq((unsigned)r.num_cus * 8);  // the quad code over what the lanes left
     if (d_lens) {
       hipLaunchKernelGGL(count_nt2_reads_probe_kernel<true>, dim3(nblk), b, 0, s, r.dev, d_words, n, L, d_counts, d_range_start, sv, d_lens);
-      hipLaunchKernelGGL((count_nt2_reads_kernel<true, true, true, true>), dim3(nblk), b, 0, s, r.dev, d_words, n, L, d_counts, d_range_start, sv, d_lens);
+      if (lanes) {
+        static const unsigned gl = resident_grid(r, lcx_lane_kernel<true, true, false>);
+        hipLaunchKernelGGL((lcx_lane_kernel<true, true, false>), dim3(gl), b, 0, s, r.dev, d_words, L, d_counts, d_range_start, sv, fb, nblk, d_lens, sv.pool_ctr, (unsigned long long*)nullptr);
+        hipLaunchKernelGGL(count_nt2_reads_pool_kernel<true>, gq, b, 0, s, r.dev, d_words, L, d_counts, d_range_start, fb, d_lens);
+      } else hipLaunchKernelGGL((count_nt2_reads_kernel<true, true, true, true>), dim3(nblk), b, 0, s, r.dev, d_words, n, L, d_counts, d_range_start, sv, d_lens);
     } else {
       hipLaunchKernelGGL(count_nt2_reads_probe_kernel<false>, dim3(nblk), b, 0, s, r.dev, d_words, n, L, d_counts, d_range_start, sv, d_lens);
-      hipLaunchKernelGGL((count_nt2_reads_kernel<true, true, true, false>), dim3(nblk), b, 0, s, r.dev, d_words, n, L, d_counts, d_range_start, sv, d_lens);
+      if (lanes) {
+        static const unsigned gl = resident_grid(r, lcx_lane_kernel<true, false, false>);
+        hipLaunchKernelGGL((lcx_lane_kernel<true, false, false>), dim3(gl), b, 0, s, r.dev, d_words, L, d_counts, d_range_start, sv, fb, nblk, d_lens, sv.pool_ctr, (unsigned long long*)nullptr);
+        hipLaunchKernelGGL(count_nt2_reads_pool_kernel<false>, gq, b, 0, s, r.dev, d_words, L, d_counts, d_range_start, fb, d_lens);
+      } else hipLaunchKernelGGL((count_nt2_reads_kernel<true, true, true, false>), dim3(nblk), b, 0, s, r.dev, d_words, n, L, d_counts, d_range_start, sv, d_lens);
     }
     HIP_CHECK(hipGetLastError());
     return;
@@ -1057,25 +1105,22 @@ void launch_count_nt2(Replica& r, const uint64_t* d_words, uint64_t n, int L, ui
   }
   if (kmode == 3 && seeded && n < (1ull << 32)) {
     // two-phase: per-lane seed probes decide most queries, the quad machinery resumes the survivors
-    Replica::SurvScratch* sc = surv_scratch(r, s);
-    const unsigned nblk = (unsigned)r.num_cus * 8;                       // both phases use this grid
-    const uint64_t per_block = ((n + (uint64_t)nblk * 256 - 1) / ((uint64_t)nblk * 256)) * 256;  // queries a block sees
-    const uint64_t total = per_block * nblk;
-    if (sc->cap < total) {
-      HIP_CHECK(hipStreamSynchronize(s));
-      sc->w.alloc(total); sc->range.alloc(total); sc->q.alloc(total);
-      if (!sc->count.p) sc->count.alloc(nblk);
-      sc->cap = sc->cap_q = total;
-    }
-    const Nt2Survivors sv{sc->w.p, sc->range.p, sc->q.p, sc->count.p, per_block};
-    const dim3 gp(nblk);
+    const bool lanes = !rung && lcx_lanes(r);
+    Nt2Survivors sv, fb;
+    unsigned nblk = 0;  // both phases of the quad schedule use this grid
+    two_phase_lists(r, s, n, lanes, &sv, &fb, &nblk);
+    const dim3 gp(nblk), gq((unsigned)r.num_cus * 8);
     // survivors of phase 1 use seed-and-verify whenever its accelerators are resident (cheap: random batches barely
     // reach phase 2); the single-kernel schedules use it only on request (awry_set_verify_kmers)
     const bool vfy = r.dev.text4 != nullptr && r.dev.dense_ratio == 1;
 #define AWRY_LAUNCH_TWO_PHASE(T, V)                                                                                 \
   do {                                                                                                             \
     hipLaunchKernelGGL((count_nt2_probe_kernel<T, V>), gp, b, 0, s, dv, d_words, n, L, d_counts, sv, d_tally);     \
-    hipLaunchKernelGGL((count_nt2_resume_kernel<T, V>), gp, b, 0, s, dv, sv, L, d_counts, d_tally);                \
+    if (lanes) {                                                                                                   \
+      static const unsigned gl = resident_grid(r, lcx_lane_kernel<false, false, T>);                               \
+      hipLaunchKernelGGL((lcx_lane_kernel<false, false, T>), dim3(gl), b, 0, s, dv, (const uint64_t*)nullptr, L, d_counts, (uint64_t*)nullptr, sv, fb, nblk, (const uint32_t*)nullptr, sv.pool_ctr, d_tally); \
+      hipLaunchKernelGGL(count_nt2_resume_pool_kernel<T>, gq, b, 0, s, dv, fb, L, d_counts, d_tally);              \
+    } else hipLaunchKernelGGL((count_nt2_resume_kernel<T, V>), gp, b, 0, s, dv, sv, L, d_counts, d_tally);         \
   } while (0)
     if (d_tally) { if (vfy) AWRY_LAUNCH_TWO_PHASE(true, true); else AWRY_LAUNCH_TWO_PHASE(true, false); }
     else { if (vfy) AWRY_LAUNCH_TWO_PHASE(false, true); else AWRY_LAUNCH_TWO_PHASE(false, false); }
@@ -2295,6 +2340,82 @@ int awry_save(awry_index_t* idx, const char* path) {
 
 void awry_free(awry_index_t* idx) { delete idx; }
 
+namespace {
+// The first batch call of a process used to pay for what every later one finds in place: the lanes' pinned staging and device
+// buffers, their events, the worker pool's threads and the pinned result arrays of the locate path (4 M 101-bp reads: 30 ms
+// for the first awry_locate_batch, 6 ms from the third on).  awry_set_devices sets all of it up for the chunk sizes the
+// host paths use (2^20 queries of up to 128 letters), so that call #1 costs what call #3 does.  AWRY_PREWARM=0 skips it.
+void prewarm_host_paths(Replica& r) {
+  static const bool off = getenv("AWRY_PREWARM") && !strcmp(getenv("AWRY_PREWARM"), "0");
+  if (off) return;
+  HIP_CHECK(hipSetDevice(r.device));
+  (void)HostPool::instance();
+  const bool nt = r.dev.alphabet == NUCLEOTIDE;
+  const uint64_t cap = 1u << 20, W = 4;  // one chunk of the host paths; W words per query cover reads of up to 128 letters
+  std::lock_guard<std::mutex> lane_lock(r.lane_mu);
+  if (nt) {
+    for (int li = 0; li < Replica::NLANES; li++) {  // count_shard_hostpacked
+      PackedLane& ln = r.lanes[li];
+      ln.s = r.lane_stream[li];
+      if (!ln.done) HIP_CHECK(hipEventCreateWithFlags(&ln.done, hipEventDisableTiming));
+      if (!ln.h_bad) HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&ln.h_bad), 16, hipHostMallocDefault));
+      ln.h_words.ensure(cap * W);
+      ln.h_counts32.ensure(cap);
+      if (ln.words.n < cap * W) ln.words.alloc(cap * W);
+      if (ln.counts.n < cap) ln.counts.alloc(cap);
+      if (ln.counts32.n < cap) ln.counts32.alloc(cap);
+      if (ln.bad.n < 2) ln.bad.alloc(2);
+    }
+    for (int li = 0; li < 2; li++) {  // locate_shard_packed
+      LocateLane& ln = r.loc_lanes[li];
+      if (!ln.counted) HIP_CHECK(hipEventCreateWithFlags(&ln.counted, hipEventDisableTiming));
+      if (!ln.located) HIP_CHECK(hipEventCreateWithFlags(&ln.located, hipEventDisableTiming));
+      if (ln.words.n < cap * W) ln.words.alloc(cap * W);
+      ln.h_words.ensure(cap * W);
+      if (ln.rstart.n < cap) ln.rstart.alloc(cap);
+      if (ln.counts.n < cap) ln.counts.alloc(cap);
+      if (ln.hit_off.n < cap + 1) ln.hit_off.alloc(cap + 1);
+      if (ln.scratch.n < scan_tiles(cap) + 1) ln.scratch.alloc(scan_tiles(cap) + 1);
+      if (ln.bad.n < 2) ln.bad.alloc(2);
+      ln.h_meta.ensure(3);
+      if (ln.gpos.n < cap + cap / 4) ln.gpos.alloc(cap + cap / 4);
+      if (ln.pos.n < 2 * (cap + cap / 4)) ln.pos.alloc(2 * (cap + cap / 4));
+    }
+    // scratch of the two-phase schedules on the lane streams (survivor lists of a full chunk)
+    for (int li = 0; li < Replica::NLANES; li++) {
+      Replica::SurvScratch* sc = surv_scratch(r, r.lane_stream[li]);
+      const unsigned nblk = (unsigned)r.num_cus * 8;
+      const uint64_t per_block = ((cap + (uint64_t)nblk * 256 - 1) / ((uint64_t)nblk * 256)) * 256, total = per_block * nblk;
+      if (sc->cap < total) { sc->w.alloc(total); sc->range.alloc(total); sc->q.alloc(total); sc->cap = sc->cap_q = total; }
+      if (!sc->count.p) sc->count.alloc(nblk);
+      if (!sc->counters.p) sc->counters.alloc(8);
+    }
+  }
+  // a stream's hardware queue, the copy engines' paths and a kernel's code are set up on first use (17 ms of "enqueue" in the
+  // first awry_count_batch of a process): one tiny round trip per lane stream -- copy in, kernel, copy out -- does that here
+  if (nt)
+    for (int li = 0; li < Replica::NLANES; li++) {
+      PackedLane& ln = r.lanes[li];
+      hipStream_t s = r.lane_stream[li];
+      memset(ln.h_words.p, 0, 64 * 8);
+      HIP_CHECK(hipMemcpyAsync(ln.words.p, ln.h_words.p, 64 * 8, hipMemcpyHostToDevice, s));
+      launch_count_nt2(r, ln.words.p, 64, r.seed_k > 0 && r.seed_k < 31 ? r.seed_k + 1 : 31, ln.counts.p, true, s, nullptr);
+      launch_count_nt2_long(r, ln.words.p, 16, 101, ln.counts.p, nullptr, true, s, nullptr);
+      hipLaunchKernelGGL(narrow_counts_kernel, dim3(1), dim3(256), 0, s, ln.counts.p, ln.counts32.p, (uint64_t)64);
+      HIP_CHECK(hipMemcpyAsync(ln.h_counts32.p, ln.counts32.p, 64 * 4, hipMemcpyDeviceToHost, s));
+      HIP_CHECK(hipStreamSynchronize(s));
+    }
+  // pinned result arrays of one typical locate call (offsets, positions, (record, offset) pairs of a few million hits):
+  // taken from the process-wide pool and handed back, so that the first call finds them cached
+  static std::once_flag once;
+  std::call_once(once, [] {
+    void* blocks[3] = {PinnedPool::instance().get(64u << 20), PinnedPool::instance().get(64u << 20), PinnedPool::instance().get(128u << 20)};
+    for (void* b : blocks)
+      if (b) release_result(b);
+  });
+}
+}  // namespace
+
 int awry_set_devices(awry_index_t* idx, const int* device_ids, int n_devices) {
   return guarded([&] {
     require(idx != nullptr, "null index");
@@ -2316,6 +2437,7 @@ int awry_set_devices(awry_index_t* idx, const int* device_ids, int n_devices) {
       for (auto& e : errs) if (e) std::rethrow_exception(e);
     }
     idx->reps = std::move(reps);
+    for (auto& r : idx->reps) prewarm_host_paths(*r);
   });
 }
 

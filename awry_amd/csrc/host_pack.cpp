@@ -67,6 +67,7 @@ struct HostPool::Impl {
   std::vector<std::thread> workers;
   std::mutex slot_mu;                 // guards slot[] and the taking of a reference
   Job* slot[SLOTS] = {nullptr};
+  std::atomic<uint32_t> posted{0};    // bit s: slot s holds a job (a hint read without the lock)
   std::mutex mu;                      // sleeping workers
   std::condition_variable cv;
   std::atomic<uint64_t> epoch{0};     // bumped whenever a job is posted
@@ -98,8 +99,10 @@ struct HostPool::Impl {
     for (;;) {
       const uint64_t e = epoch.load(std::memory_order_acquire);
       bool did = false;
+      const uint32_t hint = posted.load(std::memory_order_acquire);
       for (int s = 0; s < SLOTS; s++)
-        if (Job* j = take(s)) {
+        if (((hint >> s) & 1u) == 0) continue;
+        else if (Job* j = take(s)) {
           work(*j);
           j->refs.fetch_sub(1, std::memory_order_acq_rel);
           did = true;
@@ -157,7 +160,7 @@ void HostPool::run(uint64_t n, const std::function<void(uint64_t)>& fn) {
   {
     std::lock_guard<std::mutex> lk(p.slot_mu);
     for (int s = 0; s < Impl::SLOTS && mine < 0; s++)
-      if (!p.slot[s]) { p.slot[s] = &job; mine = s; }
+      if (!p.slot[s]) { p.slot[s] = &job; mine = s; p.posted.fetch_or(1u << s, std::memory_order_release); }
   }
   if (mine < 0) {  // every slot taken (more than 32 concurrent callers): inline
     for (uint64_t i = 0; i < n; i++) fn(i);
@@ -172,6 +175,7 @@ void HostPool::run(uint64_t n, const std::function<void(uint64_t)>& fn) {
   {
     std::lock_guard<std::mutex> lk(p.slot_mu);  // no new references after this
     p.slot[mine] = nullptr;
+    p.posted.fetch_and(~(1u << mine), std::memory_order_release);
   }
   // the items other threads are still finishing (the tail of the job: short)
   for (unsigned spins = 0; job.finished.load(std::memory_order_acquire) < n || job.refs.load(std::memory_order_acquire) != 0; spins++) {

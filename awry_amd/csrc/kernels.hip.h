@@ -1250,6 +1250,10 @@ struct Nt2Survivors {
   uint32_t* q;                 // original query index
   uint32_t* count;             // survivors per phase-1 block (block b owns slots [b * cap, (b + 1) * cap))
   uint64_t cap;                // slots per block
+  // (nullable) what lcx_lane_kernel needs at zero when it starts: its device-wide batch counter and the length of its LF
+  // list; the probe pass of the same launch sequence clears them
+  unsigned long long* pool_ctr = nullptr;
+  uint32_t* lf_count = nullptr;
 };
 
 // VERIFY (dense SA + 4-bit text resident): a probed singleton whose BWT symbol matched is not handed to phase 2 but
@@ -1268,6 +1272,10 @@ __global__ __launch_bounds__(256) void count_nt2_probe_kernel(DevIndex ix, const
   __shared__ uint32_t s_vq[VERIFY ? 4 : 1][VQ];   //   query index,
   __shared__ uint8_t s_vn[VERIFY ? 4 : 1][VQ];    //   number of candidate rows (1..VMULTI)
   if (threadIdx.x == 0) s_count = 0;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (sv.pool_ctr) *sv.pool_ctr = 0;
+    if (sv.lf_count) *sv.lf_count = 0;
+  }
   __syncthreads();
   const int lane = threadIdx.x & 63, wv_id = threadIdx.x >> 6;
   const SeedEntry* __restrict__ seed = ix.seed;
@@ -1422,17 +1430,17 @@ __global__ __launch_bounds__(256) void count_nt2_probe_kernel(DevIndex ix, const
 // (batches of k-mers that really occur in the text survive phase 1 wholesale; comparing their <= 31 remaining letters
 // with the text costs ~2 lines per candidate instead of one line per letter).  Random batches barely reach this kernel,
 // so the extra state costs them nothing -- which is why the k-mer path can keep verify on by default.
+// (the body of count_nt2_resume_kernel as a block-level function: lcx_lane_kernel runs it over what its lanes left undecided)
 template <bool TALLY, bool VERIFY>
-__global__ __launch_bounds__(256) void count_nt2_resume_kernel(DevIndex ix, Nt2Survivors sv, int L, uint64_t* __restrict__ counts,
-                                                               unsigned long long* __restrict__ tally) {
+__device__ __forceinline__ void resume_block_list(const DevIndex& ix, const Nt2Survivors& sv, uint64_t region, uint64_t ns, int L,
+                                                  uint64_t* __restrict__ counts, unsigned long long* __restrict__ tally, bool allow_lcx,
+                                                  uint64_t r_start, uint64_t r_stride) {
   const int l = threadIdx.x & 3;
-  const uint64_t ns = sv.count[blockIdx.x];
-  const uint64_t region = (uint64_t)blockIdx.x * sv.cap;
-  uint64_t r = threadIdx.x >> 2;  // 64 quads per block walk the block's list
+  uint64_t r = r_start;  // the quads that walk this list: r_start, r_start + r_stride, ...
   const uint64_t* __restrict__ blocks = ix.blocks;
   const int k = ix.seed_k;
   const int verify_after = (int)ix.verify_after;
-  const bool lcx = VERIFY && ix.lcx_key != nullptr;
+  const bool lcx = VERIFY && ix.lcx_key != nullptr && allow_lcx;
   const uint32_t cA = (uint32_t)ix.prefix_sums[1], cC = (uint32_t)ix.prefix_sums[2], cG = (uint32_t)ix.prefix_sums[3],
                  cN = (uint32_t)ix.prefix_sums[4], cT = (uint32_t)ix.prefix_sums[5], cEnd = (uint32_t)ix.prefix_sums[6];
   bool have = r < ns, fresh = true;
@@ -1538,7 +1546,7 @@ __global__ __launch_bounds__(256) void count_nt2_resume_kernel(DevIndex ix, Nt2S
       if (mode == 5 && vj >= (int)b_inc) { finished = true; out_count = vhits; }
       if (finished) {
         if (l == 0) counts[qidx] = out_count;
-        r += 64;
+        r += r_stride;
         have = r < ns;
         fresh = true;
         mode = 0;
@@ -1555,6 +1563,20 @@ __global__ __launch_bounds__(256) void count_nt2_resume_kernel(DevIndex ix, Nt2S
       atomicAdd(&tally[7], (unsigned long long)t_rp);
     }
   }
+}
+
+template <bool TALLY, bool VERIFY>
+__global__ __launch_bounds__(256) void count_nt2_resume_kernel(DevIndex ix, Nt2Survivors sv, int L, uint64_t* __restrict__ counts,
+                                                               unsigned long long* __restrict__ tally) {
+  resume_block_list<TALLY, VERIFY>(ix, sv, (uint64_t)blockIdx.x * sv.cap, (uint64_t)sv.count[blockIdx.x], L, counts, tally, true, threadIdx.x >> 2, 64);
+}
+// one device-wide list (sv.count[0] records at sv.w / range / q [0 ..)), walked by all quads of the grid with LF steps: what
+// lcx_lane_kernel could not settle
+template <bool TALLY>
+__global__ __launch_bounds__(256) void count_nt2_resume_pool_kernel(DevIndex ix, Nt2Survivors sv, int L, uint64_t* __restrict__ counts,
+                                                                    unsigned long long* __restrict__ tally) {
+  resume_block_list<TALLY, true>(ix, sv, 0, (uint64_t)sv.count[0], L, counts, tally, false,
+                                 ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 2, ((uint64_t)gridDim.x * blockDim.x) >> 2);
 }
 
 // v2 of the hot kernel: the query and result streams are staged through LDS in wave-private chunks so that
@@ -1906,16 +1928,17 @@ __global__ __launch_bounds__(256) void pack_nt2_tile_kernel(const uint8_t* __res
 // LIST: the quads of block b work through the reads block b of count_nt2_reads_probe_kernel left undecided
 // (sv.q / sv.count, same grid) instead of all n reads.
 // RAGGED: read q has lens[q] letters (1 <= lens[q] <= L); L only sets the stride of W words per read.
-template <bool USE_SEED, bool VERIFY, bool LIST = false, bool RAGGED = false>
-__global__ __launch_bounds__(256) void count_nt2_reads_kernel(DevIndex ix, const uint64_t* __restrict__ queries, uint64_t n, int L,
-                                                              uint64_t* __restrict__ counts, uint64_t* __restrict__ range_start,
-                                                              Nt2Survivors sv = Nt2Survivors{}, const uint32_t* __restrict__ lens = nullptr) {
+// (the kernel's body as a block-level function -- LIST: the block's quads work through list_q[0 .. n) -- so that
+//  lcx_lane_kernel can run it over what its lanes left undecided; allow_lcx = false there: those reads take LF steps)
+template <bool USE_SEED, bool VERIFY, bool LIST, bool RAGGED>
+__device__ __forceinline__ void reads_body(const DevIndex& ix, const uint64_t* __restrict__ queries, uint64_t n, int L,
+                                           uint64_t* __restrict__ counts, uint64_t* __restrict__ range_start,
+                                           const uint32_t* __restrict__ list_q, const uint32_t* __restrict__ lens, bool allow_lcx,
+                                           uint64_t r_start = ~0ull, uint64_t r_stride = 64) {
   const int l = threadIdx.x & 3;
   const uint64_t nquads = ((uint64_t)gridDim.x * blockDim.x) >> 2;
-  const uint64_t region = LIST ? (uint64_t)blockIdx.x * sv.cap : 0;
-  uint64_t r = threadIdx.x >> 2;  // LIST: position in the block's list
-  if (LIST) n = sv.count[blockIdx.x];
-  uint64_t q = LIST ? (r < n ? sv.q[region + r] : 0) : ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 2;
+  uint64_t r = r_start == ~0ull ? threadIdx.x >> 2 : r_start;  // LIST: position in the list (a block's own: its 64 quads)
+  uint64_t q = LIST ? (r < n ? list_q[r] : 0) : ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 2;
   const uint64_t* __restrict__ blocks = ix.blocks;
   const SeedEntry* __restrict__ seed = ix.seed;
   const uint32_t* __restrict__ dense = ix.dense_sa;
@@ -1924,7 +1947,7 @@ __global__ __launch_bounds__(256) void count_nt2_reads_kernel(DevIndex ix, const
   const int verify_after = (int)ix.verify_after;
   // left-context index (layout.h): a seed range of 2+ rows is narrowed by a search over its bucket's keys -- the 32 letters
   // left of the seed window in log16(rows) lines -- instead of one LF step per letter; what is left is compared with the text
-  const bool lcx = USE_SEED && VERIFY && ix.lcx_key != nullptr;
+  const bool lcx = USE_SEED && VERIFY && ix.lcx_key != nullptr && allow_lcx;
   const uint32_t cA = (uint32_t)ix.prefix_sums[1], cC = (uint32_t)ix.prefix_sums[2], cG = (uint32_t)ix.prefix_sums[3],
                  cN = (uint32_t)ix.prefix_sums[4], cT = (uint32_t)ix.prefix_sums[5], cEnd = (uint32_t)ix.prefix_sums[6];
   bool have = LIST ? r < n : q < n, fresh = true;
@@ -2096,9 +2119,9 @@ __global__ __launch_bounds__(256) void count_nt2_reads_kernel(DevIndex ix, const
           if (range_start) range_start[q] = out_rs;
         }
         if (LIST) {
-          r += 64;
+          r += r_stride;
           have = r < n;
-          q = have ? sv.q[region + r] : 0;
+          q = have ? list_q[r] : 0;
         } else {
           q += nquads;
           have = q < n;
@@ -2108,6 +2131,22 @@ __global__ __launch_bounds__(256) void count_nt2_reads_kernel(DevIndex ix, const
       }
     }
   }
+}
+
+template <bool USE_SEED, bool VERIFY, bool LIST = false, bool RAGGED = false>
+__global__ __launch_bounds__(256) void count_nt2_reads_kernel(DevIndex ix, const uint64_t* __restrict__ queries, uint64_t n, int L,
+                                                              uint64_t* __restrict__ counts, uint64_t* __restrict__ range_start,
+                                                              Nt2Survivors sv = Nt2Survivors{}, const uint32_t* __restrict__ lens = nullptr) {
+  if (LIST) reads_body<USE_SEED, VERIFY, LIST, RAGGED>(ix, queries, (uint64_t)sv.count[blockIdx.x], L, counts, range_start, sv.q + (uint64_t)blockIdx.x * sv.cap, lens, true);
+  else reads_body<USE_SEED, VERIFY, LIST, RAGGED>(ix, queries, n, L, counts, range_start, nullptr, lens, true);
+}
+// one device-wide list of reads (sv.count[0] of them at sv.q[0 ..)), walked by all quads of the grid with LF steps: what
+// lcx_lane_kernel could not settle
+template <bool RAGGED>
+__global__ __launch_bounds__(256) void count_nt2_reads_pool_kernel(DevIndex ix, const uint64_t* __restrict__ queries, int L, uint64_t* __restrict__ counts,
+                                                                   uint64_t* __restrict__ range_start, Nt2Survivors sv, const uint32_t* __restrict__ lens) {
+  reads_body<true, true, true, RAGGED>(ix, queries, (uint64_t)sv.count[0], L, counts, range_start, sv.q, lens, false,
+                                       ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 2, ((uint64_t)gridDim.x * blockDim.x) >> 2);
 }
 
 // Phase 1 of the two-phase schedule for reads (seed table + dense SA + 4-bit text resident, 3 <= L - k): one read per
@@ -2128,6 +2167,10 @@ __global__ __launch_bounds__(256) void count_nt2_reads_probe_kernel(DevIndex ix,
   __shared__ uint16_t s_vl[RAGGED ? 4 : 1][VQ];  // RAGGED: the read's length (<= 512 on this path)
   __shared__ uint64_t s_vw[4][3][VQ];  // the letters left of the seed window of a queued read (<= 96 of them: three words)
   if (threadIdx.x == 0) s_count = 0;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (sv.pool_ctr) *sv.pool_ctr = 0;
+    if (sv.lf_count) *sv.lf_count = 0;
+  }
   __syncthreads();
   const int lane = threadIdx.x & 63, wv_id = threadIdx.x >> 6;
   const SeedEntry* __restrict__ seed = ix.seed;
@@ -2272,7 +2315,14 @@ __global__ __launch_bounds__(256) void count_nt2_reads_probe_kernel(DevIndex ix,
         unsigned int slot0 = 0;
         if (lane == 0) slot0 = atomicAdd(&s_count, (unsigned int)__popcll(sm));
         slot0 = __shfl(slot0, 0, 64);
-        if (survivor) sv.q[region + slot0 + (uint64_t)__popcll(sm & lane_lt)] = (uint32_t)qv[h];
+        if (survivor) {
+          const uint64_t s = region + slot0 + (uint64_t)__popcll(sm & lane_lt);
+          sv.q[s] = (uint32_t)qv[h];
+          if (sv.range) {  // for lcx_lane_kernel: the probed entry (~0: not probed) and the <= 32 letters left of the seed window
+            sv.range[s] = probe[h] ? ((uint64_t)e.sp | ((uint64_t)(cnt | (e.cnt & (SEED_LCX_NONE | SEED_LCX_TAIL))) << 32)) : ~0ull;
+            sv.w[s] = probe[h] ? lcx_read_ctx(queries + qv[h] * W, W, (RAGGED ? (int)lens[qv[h]] : L) - k) : 0ull;
+          }
+        }
       }
     }
   }
@@ -2758,6 +2808,10 @@ __global__ __launch_bounds__(256) void locate_walk_nt_lane_kernel(DevIndex ix, u
     atomicAdd(&tally[1], t_hits);
   }
 }
+
+}  // namespace awry
+#include "lcx_kernels.hip.h"
+namespace awry {
 
 // ------------------------------------------------------------------------------------------------
 // Wide rows: nucleotide indexes of 2^32 rows or more (the reference is u64 throughout, src/search.rs:7).  The same quad

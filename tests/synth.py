@@ -128,7 +128,7 @@ REPEAT_FAMILIES = (
 )
 SATELLITE_FRACTION, SATELLITE_ARRAYS, SATELLITE_UNIT = 0.020, 120, 171  # per-copy divergence 2 %, array-specific unit variants 5 %
 # exact tandem arrays, each with a unit of its own: (unit lengths, array lengths, fraction) -- microsatellites and minisatellites
-SIMPLE_TANDEM = (((2, 6), (20, 200), 0.003), ((20, 60), (2000, 20000), 0.0005))
+SIMPLE_TANDEM = (((2, 6), (20, 100), 0.003), ((20, 60), (500, 5000), 0.0005))  # (microsatellites stay below read length, as in real genomes)
 SEGDUP_FRACTION, SEGDUP_MIN, SEGDUP_MAX = 0.048, 10_000, 200_000        # copies of existing stretches at 1 .. 5 % divergence
 GAP_FRACTION_BIG, GAP_BIG, GAP_FRACTION_SMALL, GAP_SMALL = 0.043, 24, 0.007, 500
 

@@ -1600,3 +1600,38 @@ def test_ecoli_scale_21mers_against_the_oracle(oracle):
     assert np.array_equal(off, ooff) and np.array_equal(gpos, ogpos) and np.array_equal(pos, opos)
     for q in (q2d[0], q2d[10_000], q2d[19_999]):
         assert ix.count_string(bytes(q)) == oi.count_string(bytes(q))
+
+
+@pytest.mark.parametrize("tail_len", [3, 7, 8, 9, 15, 17, 24])
+def test_ragged_amino_batch_that_ends_with_its_allocation(oracle, tail_len):
+    """the amino k-mer pass reads a query with 8-byte loads anchored at the query's END (and at its start only where 8 bytes
+    exist), so a caller's buffer may end with its last query: the batch is uploaded into an allocation of exactly its own
+    size (no slack), with the last -- and the first -- query shorter than a word, and counted against the oracle"""
+    text, st, hd = synth.make_text(120000, 1, 41, 12, 0.01)
+    ix = gpu_index(text, 1, 8, 0, st, hd)
+    oi = oracle.OracleIndex.from_text(text, 1, 8, 0, st, hd)
+    k = ix.seed_kmer_len()
+    rng = np.random.default_rng(tail_len)
+    nq = 6000  # enough queries for the two-phase schedule (>= 4096)
+    lens = rng.integers(max(k, 1), 25, size=nq)
+    lens[0] = max(k, 3)         # a first query within the buffer's first seven bytes
+    lens[-1] = max(k, tail_len)  # the last query ends the allocation
+    qo = np.zeros(nq + 1, dtype=np.uint64)
+    qo[1:] = np.cumsum(lens)
+    starts = rng.integers(0, len(text) - 30, size=nq)
+    idx = np.repeat(starts, lens) + (np.arange(int(qo[-1])) - np.repeat(qo[:-1].astype(np.int64), lens))
+    qb = text[idx].copy()
+    qb[qb == ord("$")] = ord("A")
+    want, _ = oi.parallel_count(qb, qo, 4)
+    d_q = ix.dev_upload(qb)           # exactly len(qb) bytes
+    d_off = ix.dev_upload(qo)
+    d_c = ix.dev_malloc(8 * nq)
+    d_s = ix.dev_malloc(nq)
+    try:
+        ix.dev_count_ascii(d_q, d_off, nq, d_c, None, d_s)
+        ix.dev_synchronize()
+        assert np.array_equal(ix.dev_download(d_c, (nq,), np.uint64), want)
+        assert int(ix.dev_download(d_s, (nq,), np.uint8).max()) == 0
+    finally:
+        for p in (d_q, d_off, d_c, d_s):
+            ix.dev_free(p)

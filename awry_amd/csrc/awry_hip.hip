@@ -206,7 +206,7 @@ struct Replica {
     DevBuf<uint64_t> w, range;
     DevBuf<uint32_t> q, count;
     uint64_t cap = 0, cap_q = 0;
-    // what lcx_lane_kernel leaves for the quad code: a second set of block-private lists with the same geometry
+    // what lcx_quad_reads_kernel leaves for the LF pass: one device-wide list (fcount[0] slots)
     DevBuf<uint64_t> fw, frange;
     DevBuf<uint32_t> fq, fcount;
     uint64_t fcap = 0;
@@ -965,10 +965,10 @@ Replica::SurvScratch* surv_scratch(Replica& r, hipStream_t s) {
   return slot.get();
 }
 
-// phase 2 with one survivor per lane (lcx_lane_kernel) whenever the left-context index is resident; AWRY_LCX_LANES=0 keeps the
-// quad kernels (which search the index four lanes per query) for A/B
+// reads: phase 2 as a pooled search pass (lcx_quad_reads_kernel) + LF pass whenever the left-context index is resident;
+// AWRY_LCX_POOL=0 keeps count_nt2_reads_kernel<.., LIST> (block b works through block b's list) for A/B
 bool lcx_lanes(const Replica& r) {
-  static const bool off = getenv("AWRY_LCX_LANES") && !strcmp(getenv("AWRY_LCX_LANES"), "0");
+  static const bool off = getenv("AWRY_LCX_POOL") && !strcmp(getenv("AWRY_LCX_POOL"), "0");
   return !off && r.dev.lcx_key != nullptr && r.dev.text4 != nullptr && r.dev.dense_ratio == 1;
 }
 // the survivor lists of a two-phase launch over n queries: `in` (all three arrays) and, with lanes, the fallback lists `out`
@@ -982,23 +982,23 @@ void two_phase_lists(Replica& r, hipStream_t s, uint64_t n, bool lanes, Nt2Survi
       sc->w.alloc(total); sc->range.alloc(total); sc->q.alloc(total);
       sc->cap = sc->cap_q = total;
     }
-    if (lanes && sc->fcap < total) {
-      sc->fw.alloc(total); sc->frange.alloc(total); sc->fq.alloc(total);
+    if (lanes && sc->fcap < total) {  // (+ the chunks the waves of lcx_quad_kernel reserve and do not fill)
+      const uint64_t slack = 1ull << 21;
+      sc->fw.alloc(total + slack); sc->frange.alloc(total + slack); sc->fq.alloc(total + slack);
       sc->fcap = total;
     }
   }
   if (!sc->count.p) sc->count.alloc(nblk);
-  if (lanes && !sc->fcount.p) sc->fcount.alloc(8);  // [0] length of the LF list, [2..3] the lane pass's batch counter
+  if (lanes && !sc->fcount.p) sc->fcount.alloc(8);  // [0] length of the LF list
   *in = Nt2Survivors{sc->w.p, sc->range.p, sc->q.p, sc->count.p, per_block};
   *out = Nt2Survivors{};
   if (lanes) {
     *out = Nt2Survivors{sc->fw.p, sc->frange.p, sc->fq.p, sc->fcount.p, total};
-    in->pool_ctr = reinterpret_cast<unsigned long long*>(sc->fcount.p + 2);
     in->lf_count = sc->fcount.p;
   }
   *nblk_out = nblk;
 }
-// blocks of lcx_lane_kernel that are resident at once (its 52 KB of LDS and ~150 VGPRs allow three per CU): the grid
+// blocks of lcx_quad_kernel that are resident at once: its grid (the pool of survivors is shared out dynamically)
 template <class K>
 unsigned resident_grid(const Replica& r, K kernel) {
   int per_cu = 0;
@@ -1038,15 +1038,15 @@ void launch_count_nt2_long(Replica& r, const uint64_t* d_words, uint64_t n, int 
     if (d_lens) {
       hipLaunchKernelGGL(count_nt2_reads_probe_kernel<true>, dim3(nblk), b, 0, s, r.dev, d_words, n, L, d_counts, d_range_start, sv, d_lens);
       if (lanes) {
-        static const unsigned gl = resident_grid(r, lcx_lane_kernel<true, true, false>);
-        hipLaunchKernelGGL((lcx_lane_kernel<true, true, false>), dim3(gl), b, 0, s, r.dev, d_words, L, d_counts, d_range_start, sv, fb, nblk, d_lens, sv.pool_ctr, (unsigned long long*)nullptr);
+        static const unsigned gl = resident_grid(r, lcx_quad_reads_kernel<true>);
+        hipLaunchKernelGGL(lcx_quad_reads_kernel<true>, dim3(gl), b, 0, s, r.dev, d_words, L, d_counts, d_range_start, sv, fb, nblk, d_lens);
         hipLaunchKernelGGL(count_nt2_reads_pool_kernel<true>, gq, b, 0, s, r.dev, d_words, L, d_counts, d_range_start, fb, d_lens);
       } else hipLaunchKernelGGL((count_nt2_reads_kernel<true, true, true, true>), dim3(nblk), b, 0, s, r.dev, d_words, n, L, d_counts, d_range_start, sv, d_lens);
     } else {
       hipLaunchKernelGGL(count_nt2_reads_probe_kernel<false>, dim3(nblk), b, 0, s, r.dev, d_words, n, L, d_counts, d_range_start, sv, d_lens);
       if (lanes) {
-        static const unsigned gl = resident_grid(r, lcx_lane_kernel<true, false, false>);
-        hipLaunchKernelGGL((lcx_lane_kernel<true, false, false>), dim3(gl), b, 0, s, r.dev, d_words, L, d_counts, d_range_start, sv, fb, nblk, d_lens, sv.pool_ctr, (unsigned long long*)nullptr);
+        static const unsigned gl = resident_grid(r, lcx_quad_reads_kernel<false>);
+        hipLaunchKernelGGL(lcx_quad_reads_kernel<false>, dim3(gl), b, 0, s, r.dev, d_words, L, d_counts, d_range_start, sv, fb, nblk, d_lens);
         hipLaunchKernelGGL(count_nt2_reads_pool_kernel<false>, gq, b, 0, s, r.dev, d_words, L, d_counts, d_range_start, fb, d_lens);
       } else hipLaunchKernelGGL((count_nt2_reads_kernel<true, true, true, false>), dim3(nblk), b, 0, s, r.dev, d_words, n, L, d_counts, d_range_start, sv, d_lens);
     }
@@ -1105,22 +1105,17 @@ void launch_count_nt2(Replica& r, const uint64_t* d_words, uint64_t n, int L, ui
   }
   if (kmode == 3 && seeded && n < (1ull << 32)) {
     // two-phase: per-lane seed probes decide most queries, the quad machinery resumes the survivors
-    const bool lanes = !rung && lcx_lanes(r);
     Nt2Survivors sv, fb;
-    unsigned nblk = 0;  // both phases of the quad schedule use this grid
-    two_phase_lists(r, s, n, lanes, &sv, &fb, &nblk);
-    const dim3 gp(nblk), gq((unsigned)r.num_cus * 8);
+    unsigned nblk = 0;  // both phases use this grid
+    two_phase_lists(r, s, n, false, &sv, &fb, &nblk);
+    const dim3 gp(nblk);
     // survivors of phase 1 use seed-and-verify whenever its accelerators are resident (cheap: random batches barely
     // reach phase 2); the single-kernel schedules use it only on request (awry_set_verify_kmers)
     const bool vfy = r.dev.text4 != nullptr && r.dev.dense_ratio == 1;
 #define AWRY_LAUNCH_TWO_PHASE(T, V)                                                                                 \
   do {                                                                                                             \
     hipLaunchKernelGGL((count_nt2_probe_kernel<T, V>), gp, b, 0, s, dv, d_words, n, L, d_counts, sv, d_tally);     \
-    if (lanes) {                                                                                                   \
-      static const unsigned gl = resident_grid(r, lcx_lane_kernel<false, false, T>);                               \
-      hipLaunchKernelGGL((lcx_lane_kernel<false, false, T>), dim3(gl), b, 0, s, dv, (const uint64_t*)nullptr, L, d_counts, (uint64_t*)nullptr, sv, fb, nblk, (const uint32_t*)nullptr, sv.pool_ctr, d_tally); \
-      hipLaunchKernelGGL(count_nt2_resume_pool_kernel<T>, gq, b, 0, s, dv, fb, L, d_counts, d_tally);              \
-    } else hipLaunchKernelGGL((count_nt2_resume_kernel<T, V>), gp, b, 0, s, dv, sv, L, d_counts, d_tally);         \
+    hipLaunchKernelGGL((count_nt2_resume_kernel<T, V>), gp, b, 0, s, dv, sv, L, d_counts, d_tally);                \
   } while (0)
     if (d_tally) { if (vfy) AWRY_LAUNCH_TWO_PHASE(true, true); else AWRY_LAUNCH_TWO_PHASE(true, false); }
     else { if (vfy) AWRY_LAUNCH_TWO_PHASE(false, true); else AWRY_LAUNCH_TWO_PHASE(false, false); }

@@ -1250,9 +1250,7 @@ struct Nt2Survivors {
   uint32_t* q;                 // original query index
   uint32_t* count;             // survivors per phase-1 block (block b owns slots [b * cap, (b + 1) * cap))
   uint64_t cap;                // slots per block
-  // (nullable) what lcx_lane_kernel needs at zero when it starts: its device-wide batch counter and the length of its LF
-  // list; the probe pass of the same launch sequence clears them
-  unsigned long long* pool_ctr = nullptr;
+  // (nullable) the length of lcx_quad_reads_kernel's LF list: the probe pass of the same launch sequence clears it
   uint32_t* lf_count = nullptr;
 };
 
@@ -1272,10 +1270,7 @@ __global__ __launch_bounds__(256) void count_nt2_probe_kernel(DevIndex ix, const
   __shared__ uint32_t s_vq[VERIFY ? 4 : 1][VQ];   //   query index,
   __shared__ uint8_t s_vn[VERIFY ? 4 : 1][VQ];    //   number of candidate rows (1..VMULTI)
   if (threadIdx.x == 0) s_count = 0;
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    if (sv.pool_ctr) *sv.pool_ctr = 0;
-    if (sv.lf_count) *sv.lf_count = 0;
-  }
+  if (blockIdx.x == 0 && threadIdx.x == 0 && sv.lf_count) *sv.lf_count = 0;
   __syncthreads();
   const int lane = threadIdx.x & 63, wv_id = threadIdx.x >> 6;
   const SeedEntry* __restrict__ seed = ix.seed;
@@ -1430,7 +1425,7 @@ __global__ __launch_bounds__(256) void count_nt2_probe_kernel(DevIndex ix, const
 // (batches of k-mers that really occur in the text survive phase 1 wholesale; comparing their <= 31 remaining letters
 // with the text costs ~2 lines per candidate instead of one line per letter).  Random batches barely reach this kernel,
 // so the extra state costs them nothing -- which is why the k-mer path can keep verify on by default.
-// (the body of count_nt2_resume_kernel as a block-level function: lcx_lane_kernel runs it over what its lanes left undecided)
+// (the body of count_nt2_resume_kernel as a block-level function, with the set of list positions a quad walks as parameters)
 template <bool TALLY, bool VERIFY>
 __device__ __forceinline__ void resume_block_list(const DevIndex& ix, const Nt2Survivors& sv, uint64_t region, uint64_t ns, int L,
                                                   uint64_t* __restrict__ counts, unsigned long long* __restrict__ tally, bool allow_lcx,
@@ -1468,7 +1463,9 @@ __device__ __forceinline__ void resume_block_list(const DevIndex& ix, const Nt2S
           const uint32_t cf = (uint32_t)(rg >> 32), cnt = cf & SEED_CNT_SAT;
           steps_done = 0;
           fresh = false;
-          if (cnt == SEED_CNT_SAT) {
+          if (qidx == 0xFFFFFFFFu) {  // an empty slot of lcx_quad_reads_kernel's list: nothing to do
+            sp = 1u; ep = 0u; i = 0;
+          } else if (cnt == SEED_CNT_SAT) {
             const uint32_t c = (uint32_t)(w >> (2 * (L - 1))) & 3u;
             sp = c == 0 ? cA : (c == 1 ? cC : (c == 2 ? cG : cT));
             ep = (c == 0 ? cC : (c == 1 ? cG : (c == 2 ? cN : cEnd))) - 1;
@@ -1545,7 +1542,7 @@ __device__ __forceinline__ void resume_block_list(const DevIndex& ix, const Nt2S
       if (VERIFY && mode == 1 && vj > (int)(ep - sp)) { finished = true; out_count = vhits; }
       if (mode == 5 && vj >= (int)b_inc) { finished = true; out_count = vhits; }
       if (finished) {
-        if (l == 0) counts[qidx] = out_count;
+        if (l == 0 && qidx != 0xFFFFFFFFu) counts[qidx] = out_count;
         r += r_stride;
         have = r < ns;
         fresh = true;
@@ -1570,15 +1567,6 @@ __global__ __launch_bounds__(256) void count_nt2_resume_kernel(DevIndex ix, Nt2S
                                                                unsigned long long* __restrict__ tally) {
   resume_block_list<TALLY, VERIFY>(ix, sv, (uint64_t)blockIdx.x * sv.cap, (uint64_t)sv.count[blockIdx.x], L, counts, tally, true, threadIdx.x >> 2, 64);
 }
-// one device-wide list (sv.count[0] records at sv.w / range / q [0 ..)), walked by all quads of the grid with LF steps: what
-// lcx_lane_kernel could not settle
-template <bool TALLY>
-__global__ __launch_bounds__(256) void count_nt2_resume_pool_kernel(DevIndex ix, Nt2Survivors sv, int L, uint64_t* __restrict__ counts,
-                                                                    unsigned long long* __restrict__ tally) {
-  resume_block_list<TALLY, true>(ix, sv, 0, (uint64_t)sv.count[0], L, counts, tally, false,
-                                 ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 2, ((uint64_t)gridDim.x * blockDim.x) >> 2);
-}
-
 // v2 of the hot kernel: the query and result streams are staged through LDS in wave-private chunks so that
 // both move as whole 128-B lines (v1 fetched one line per 8-B query word and wrote one partial line per
 // 8-B result: 2 of its ~4 line requests per query).  A wave grabs a chunk of CHUNK consecutive queries with
@@ -1929,7 +1917,7 @@ __global__ __launch_bounds__(256) void pack_nt2_tile_kernel(const uint8_t* __res
 // (sv.q / sv.count, same grid) instead of all n reads.
 // RAGGED: read q has lens[q] letters (1 <= lens[q] <= L); L only sets the stride of W words per read.
 // (the kernel's body as a block-level function -- LIST: the block's quads work through list_q[0 .. n) -- so that
-//  lcx_lane_kernel can run it over what its lanes left undecided; allow_lcx = false there: those reads take LF steps)
+//  lcx_quad_reads_kernel can run it over what its lanes left undecided; allow_lcx = false there: those reads take LF steps)
 template <bool USE_SEED, bool VERIFY, bool LIST, bool RAGGED>
 __device__ __forceinline__ void reads_body(const DevIndex& ix, const uint64_t* __restrict__ queries, uint64_t n, int L,
                                            uint64_t* __restrict__ counts, uint64_t* __restrict__ range_start,
@@ -1969,7 +1957,10 @@ __device__ __forceinline__ void reads_body(const DevIndex& ix, const uint64_t* _
       const uint64_t* qw = queries + q * W;
       bool finished = false;
       uint64_t out_count = 0, out_rs = 0;
-      if (mode == 0) {
+      const bool hole = LIST && q == 0xFFFFFFFFull;  // an empty slot of lcx_quad_reads_kernel's list: nothing to do
+      if (hole) {
+        finished = true;
+      } else if (mode == 0) {
         if (fresh) {
           const int Lq = RAGGED ? (int)lens[q] : L;
           const bool seeded = USE_SEED && (!RAGGED || Lq >= k);  // a read shorter than the seed starts without the table
@@ -2114,7 +2105,7 @@ __device__ __forceinline__ void reads_body(const DevIndex& ix, const uint64_t* _
         }
       }
       if (finished) {
-        if (l == 0) {
+        if (l == 0 && !hole) {
           counts[q] = out_count;
           if (range_start) range_start[q] = out_rs;
         }
@@ -2141,7 +2132,7 @@ __global__ __launch_bounds__(256) void count_nt2_reads_kernel(DevIndex ix, const
   else reads_body<USE_SEED, VERIFY, LIST, RAGGED>(ix, queries, n, L, counts, range_start, nullptr, lens, true);
 }
 // one device-wide list of reads (sv.count[0] of them at sv.q[0 ..)), walked by all quads of the grid with LF steps: what
-// lcx_lane_kernel could not settle
+// lcx_quad_reads_kernel could not settle
 template <bool RAGGED>
 __global__ __launch_bounds__(256) void count_nt2_reads_pool_kernel(DevIndex ix, const uint64_t* __restrict__ queries, int L, uint64_t* __restrict__ counts,
                                                                    uint64_t* __restrict__ range_start, Nt2Survivors sv, const uint32_t* __restrict__ lens) {
@@ -2167,10 +2158,7 @@ __global__ __launch_bounds__(256) void count_nt2_reads_probe_kernel(DevIndex ix,
   __shared__ uint16_t s_vl[RAGGED ? 4 : 1][VQ];  // RAGGED: the read's length (<= 512 on this path)
   __shared__ uint64_t s_vw[4][3][VQ];  // the letters left of the seed window of a queued read (<= 96 of them: three words)
   if (threadIdx.x == 0) s_count = 0;
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    if (sv.pool_ctr) *sv.pool_ctr = 0;
-    if (sv.lf_count) *sv.lf_count = 0;
-  }
+  if (blockIdx.x == 0 && threadIdx.x == 0 && sv.lf_count) *sv.lf_count = 0;
   __syncthreads();
   const int lane = threadIdx.x & 63, wv_id = threadIdx.x >> 6;
   const SeedEntry* __restrict__ seed = ix.seed;
@@ -2318,7 +2306,7 @@ __global__ __launch_bounds__(256) void count_nt2_reads_probe_kernel(DevIndex ix,
         if (survivor) {
           const uint64_t s = region + slot0 + (uint64_t)__popcll(sm & lane_lt);
           sv.q[s] = (uint32_t)qv[h];
-          if (sv.range) {  // for lcx_lane_kernel: the probed entry (~0: not probed) and the <= 32 letters left of the seed window
+          if (sv.range) {  // for lcx_quad_reads_kernel: the probed entry (~0: not probed) and the <= 32 letters left of the seed window
             sv.range[s] = probe[h] ? ((uint64_t)e.sp | ((uint64_t)(cnt | (e.cnt & (SEED_LCX_NONE | SEED_LCX_TAIL))) << 32)) : ~0ull;
             sv.w[s] = probe[h] ? lcx_read_ctx(queries + qv[h] * W, W, (RAGGED ? (int)lens[qv[h]] : L) - k) : 0ull;
           }

@@ -1,42 +1,44 @@
 // lcx_kernels.hip.h -- phase 2 of the two-phase count schedules when the left-context index (layout.h, lcx.hip.h) is
-// resident: one survivor per LANE.  Included at the end of kernels.hip.h.
+// resident.  Included at the end of kernels.hip.h.
 //
-// The quad kernels (count_nt2_resume_kernel, count_nt2_reads_kernel) search a bucket with four lanes per query: 16
-// searches per wave, each a chain of 3..6 dependent line reads -- ~100 K line requests in flight on the chip, a third of
-// what the memory system needs to reach its random-line rate (measured: 14 G lines/s on k-mers drawn from a repeat-rich
-// GRCh38-scale text).  Here every lane carries its own search, 64 per wave, and the 128-B nodes the lanes of a wave need in
-// an iteration are fetched COOPERATIVELY -- eight lanes per node, so one load instruction covers eight whole lines, as in
-// locate_walk_nt_lane_kernel -- and handed to their lanes through a wave-private LDS tile.  A lane is a small state
-// machine (FETCH the survivor record, TAIL count, SEARCH levels, candidate / tail entries against the text); every
-// iteration first issues the one load group each lane's state needs and only then consumes the results.
-// The block-private survivor lists of the probe pass are consumed as ONE pool: a block keeps the prefix sums of the list
-// lengths in LDS and its waves draw batches of 64 items from a device-wide counter, so every wave has work until the pool is
-// empty whatever the lists' lengths (a random batch leaves a few survivors per list, a batch from repeats thousands).
-// What this pass cannot settle -- saturated or uncovered buckets, more candidates than are worth comparing one by one,
-// ranges the locate pass needs as rows -- goes to one device-wide list, which count_nt2_resume_pool_kernel /
-// count_nt2_reads_pool_kernel then work through with the quad code (LF steps).
+// count_nt2_resume_kernel / count_nt2_reads_kernel<.., LIST> search the index too, but they are built around LF steps: one
+// survivor per quad at a time, block b working through the list block b wrote.  A search is a chain of 3..6 dependent
+// line reads, so those kernels keep ~100 K requests in flight -- a third of what the memory system needs -- and a batch
+// from repeats leaves lists of very different lengths (measured on k-mers drawn from a repeat-rich GRCh38-scale text:
+// 14 G lines/s, 960 us for 4.3 M survivors).  This kernel does nothing but search:
+//   * the block-private survivor lists of the probe pass are consumed as ONE pool (prefix sums of the list lengths in
+//     LDS; every wave takes an equal, contiguous share), so every wave has work until the pool is empty;
+//   * per iteration a quad first issues the load group its search needs -- both bounds' nodes once they have parted -- and
+//     only then consumes it (SLOTS searches per quad: one, see the end of this file);
+//   * a search loads one 128-B node per level as two 16-B loads per lane (a 64-B half line per instruction), counts with
+//     four 64-bit compares per lane and two quad_perm DPP adds;
+//   * what it cannot settle -- saturated or uncovered buckets, more candidates than are worth comparing with the text one
+//     by one, ranges the locate pass needs as rows -- goes to ONE device-wide list that count_nt2_reads_pool_kernel works through
+//     with LF steps.
+// (A one-search-per-LANE variant with cooperative node fetches through LDS was measured first: 64 searches per wave, but
+//  ~600 instructions per wave iteration -- every lane compares all 16 keys of its node, and the lanes of a wave are in
+//  different states -- made it instruction-bound: 800 us for the same 4.3 M survivors, 9.2 ms against 14.5 for reads.)
 #pragma once
 
 namespace awry {
 
-enum : int { LL_IDLE = 0, LL_FETCH, LL_FETCH2, LL_TAILCNT, LL_SEARCH, LL_POS, LL_TXT, LL_DONE };
+enum : int { LQ_IDLE = 0, LQ_FETCH, LQ_FETCH2, LQ_TAILCNT, LQ_SEARCH, LQ_POS, LQ_TXT, LQ_DONE };
+constexpr int LCX_LF_CHUNK = 256;  // slots of the LF list a wave reserves at a time (16 quads x 2 slots append at most 32 per step)
 
 // READS: survivors of count_nt2_reads_probe_kernel (in.w = the <= 32 letters left of the seed window, in.range = the probed
-// entry, in.q = the read); else survivors of count_nt2_probe_kernel (in.w = the k-mer).  out: the lists of what is left for
-// the quad code, same geometry.  nlists block-private lists, worked through by gridDim.x blocks.
-template <bool READS, bool RAGGED, bool TALLY>
-__global__ __launch_bounds__(256) void lcx_lane_kernel(DevIndex ix, const uint64_t* __restrict__ queries, int L, uint64_t* __restrict__ counts,
-                                                       uint64_t* __restrict__ range_start, Nt2Survivors in, Nt2Survivors out, uint32_t nlists,
-                                                       const uint32_t* __restrict__ lens, unsigned long long* __restrict__ ctr,
-                                                       unsigned long long* __restrict__ tally) {
-  constexpr int ROW = 9;  // 16-B pieces per tile row: 8 + 1 of padding against bank conflicts
-  __shared__ ulonglong2 s_blk[4][64 * ROW];
+// entry or ~0, in.q = the read); else survivors of count_nt2_probe_kernel (in.w = the k-mer).  out: the device-wide list of
+// what is left for the LF kernels (out.count[0] slots, empty ones marked q = ~0; k-mers: records as the probe pass writes
+// them, with SEED_LCX_NONE set); the probe pass clears out.count[0] (Nt2Survivors::lf_count).
+template <bool READS, bool RAGGED, bool TALLY, int SLOTS>
+__device__ __forceinline__ void lcx_quad_body(const DevIndex& ix, const uint64_t* __restrict__ queries, int L, uint64_t* __restrict__ counts,
+                                              uint64_t* __restrict__ range_start, const Nt2Survivors& in, const Nt2Survivors& out, uint32_t nlists,
+                                              const uint32_t* __restrict__ lens, unsigned long long* __restrict__ tally) {
   __shared__ uint32_t s_pref[LIST_MAX_LISTS + 1];  // exclusive prefix sums of the lists' lengths
-  const int lane = threadIdx.x & 63, wv_id = threadIdx.x >> 6;
-  const uint64_t lane_lt = (1ull << lane) - 1;
+  const int lane = threadIdx.x & 63, l = lane & 3;
+  const uint64_t leader_lt = ((1ull << (lane & ~3)) - 1) & 0x1111111111111111ull;  // the leader lanes of the quads before this one
   const int k = ix.seed_k, W = (L + 31) / 32;
   const uint32_t* __restrict__ text4 = ix.text4;
-  unsigned long long t_nodes = 0, t_rp = 0, t_txt = 0;
+  uint32_t t_nodes = 0, t_rp = 0, t_txt = 0;
   uint32_t ns = 0;  // items in the pool
   {
     const uint32_t per = (nlists + blockDim.x - 1) / blockDim.x, l0 = threadIdx.x * per;
@@ -50,261 +52,296 @@ __global__ __launch_bounds__(256) void lcx_lane_kernel(DevIndex ix, const uint64
     ns = (uint32_t)tot;
   }
   __syncthreads();
-  {
-    uint32_t cur = 0, end = 0;  // wave-uniform: the unassigned rest of this wave's batch
-    bool exhausted = false;
-    int state = LL_IDLE;
-    uint64_t w = 0, qlo = 0, qhi = 0;
-    uint32_t q = 0, sp = 0, cnt = 0, inc = 0, flags = 0;
-    uint64_t item = 0;  // where this lane's survivor record lies
-    uint32_t a0 = 0, b0 = 0, a1 = 0, b1 = 0;
-    int t0 = -1, t1 = -1, i = 0;
-    uint32_t hits = 0, lb = 0, vmask = 0, vp = 0;
-    int vj = 0, vn = 0, vc = 0;   // candidate / tail entry being checked, how many there are, text chunk
-    bool tail_pass = false;
-    for (;;) {
-      const uint64_t nm = __ballot(state == LL_IDLE);
+  // Every wave owns an equal, contiguous share of the pool.  (Batches drawn from a device-wide counter were measured first:
+  // one atomic per 64 items on one address is ~12 ns each, 0.8 ms for 4.3 M survivors -- and 40 us for a batch with next to
+  // no survivors, every wave finding the counter exhausted.)  The items are alike -- a search is 2..6 dependent lines -- so
+  // equal shares end together; what is not alike (LF chains) is not done here.
+  const uint32_t nwaves = gridDim.x * 4u, wave_id = blockIdx.x * 4u + (threadIdx.x >> 6);
+  const uint32_t share = (ns + nwaves - 1) / nwaves;
+  uint32_t cur = (uint64_t)wave_id * share < ns ? wave_id * share : ns;
+  const uint32_t end = (uint64_t)cur + share < ns ? cur + share : ns;
+  uint32_t lf_base = 0, lf_used = LCX_LF_CHUNK;  // wave-uniform: this wave's current chunk of the LF list
+  uint32_t li = 0;  // wave-uniform: the list that holds item `cur` (s_pref[li] <= cur < s_pref[li + 1]); the share is walked in order
+  if (cur < end) {
+    uint32_t lo = 0, hi = nlists;
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (s_pref[mid] <= cur) lo = mid; else hi = mid; }
+    li = lo;
+  }
+  int state[SLOTS];
+  uint64_t w[SLOTS], qlo[SLOTS];  // (the upper threshold is qlo with the letters the query does not have set to ones)
+  uint32_t q[SLOTS], sp[SLOTS], cnt[SLOTS], inc[SLOTS], flags[SLOTS];
+  uint32_t a0[SLOTS], b0[SLOTS], a1[SLOTS], b1[SLOTS], vmask[SLOTS], vp[SLOTS];
+  int t0[SLOTS], t1[SLOTS], ii[SLOTS], vj[SLOTS], vn[SLOTS], vc[SLOTS];
+  bool tail_pass[SLOTS];
+#pragma unroll
+  for (int s = 0; s < SLOTS; s++) {
+    state[s] = LQ_IDLE;
+    w[s] = qlo[s] = 0;
+    q[s] = sp[s] = cnt[s] = inc[s] = flags[s] = a0[s] = b0[s] = a1[s] = b1[s] = vmask[s] = vp[s] = 0;
+    t0[s] = t1[s] = -1;
+    ii[s] = vj[s] = vn[s] = vc[s] = 0;
+    tail_pass[s] = false;
+  }
+  for (;;) {
+    // K[s][0..3], the registers a slot's loads land in: FETCH word / entry / index; TAILCNT key; POS entry; SEARCH the lane's
+    // four keys of the node; TXT the lane's text window (5 words) and query word
+    uint64_t K[SLOTS][8];  // ([4..7]: the upper bound's node once the two bounds have parted)
+#pragma unroll
+    for (int s = 0; s < SLOTS; s++)
+#pragma unroll
+      for (int u = 0; u < 8; u++) K[s][u] = 0;
+    // ---- hand out items to idle slots, in item order (quad-uniform decisions throughout); their records are asked for at once
+    bool any_busy = false;
+#pragma unroll
+    for (int s = 0; s < SLOTS; s++) {
+      const uint64_t nm = cur < end ? __ballot(state[s] == LQ_IDLE && l == 0) : 0ull;
       if (nm) {
-        if (cur == end && !exhausted) {
-          unsigned long long base = 0;
-          if (lane == 0) base = atomicAdd(&ctr[0], 64ull);
-          base = __shfl(base, 0, 64);
-          cur = base < ns ? (uint32_t)base : ns;
-          end = base + 64ull < ns ? (uint32_t)base + 64u : ns;
-          exhausted = cur == end;
-        }
-        if (exhausted && nm == ~0ull) break;
-        if (state == LL_IDLE) {
-          const uint32_t idx = cur + (uint32_t)__popcll(nm & lane_lt);
-          if (idx < end) {  // item idx of the pool: list l with s_pref[l] <= idx < s_pref[l + 1]
-            uint32_t lo = 0, hi = nlists;
-            while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (s_pref[mid] <= idx) lo = mid; else hi = mid; }
-            item = (uint64_t)lo * in.cap + (idx - s_pref[lo]);
-            state = LL_FETCH;
+        if (state[s] == LQ_IDLE) {
+          const uint32_t idx = cur + (uint32_t)__popcll(nm & leader_lt);
+          if (idx < end) {  // item idx of the pool: list lo with s_pref[lo] <= idx < s_pref[lo + 1], at or a little after li
+            uint32_t lo = li;
+            while (s_pref[lo + 1] <= idx) lo++;
+            const uint64_t item = (uint64_t)lo * in.cap + (idx - s_pref[lo]);
+            K[s][0] = in.w[item];
+            K[s][1] = in.range[item];
+            K[s][2] = in.q[item];
+            state[s] = LQ_FETCH;
           }
         }
         const uint32_t adv = cur + (uint32_t)__popcll(nm);
         cur = adv < end ? adv : end;
+        while (cur < end && s_pref[li + 1] <= cur) li++;
       }
-      // ---- SEARCH: which node does this lane need next?  (levels without a sampled row inside a bound's range are passed)
-      bool want_node = false, shared = false;
-      int bound = 0, tl = 0;
-      uint64_t nb = 0;
-      const uint64_t* node = nullptr;
-      if (state == LL_SEARCH) {
-        while (t0 >= 0 && lcx_first_sample(a0, 4 * t0) >= b0) t0--;
-        while (t1 >= 0 && lcx_first_sample(a1, 4 * t1) >= b1) t1--;
-        if (t0 < 0 && t1 < 0) state = LL_DONE;
+      any_busy = any_busy || state[s] != LQ_IDLE;
+    }
+    if (!__any(any_busy)) break;  // (idle slots were offered the rest of the share above: nothing is left)
+    // ---- per slot: what to load
+    bool want_node[SLOTS], to_lf[SLOTS], shared[SLOTS];
+    uint32_t nb0[SLOTS], nb1[SLOTS];  // the nodes the two bounds consult (levels t0 / t1; < 0: that bound is done)
+#pragma unroll
+    for (int s = 0; s < SLOTS; s++) {
+      want_node[s] = to_lf[s] = shared[s] = false;
+      nb0[s] = nb1[s] = 0;
+      bool settle = false;
+      uint64_t out_count = 0, out_rs = 0;
+      if (state[s] == LQ_SEARCH) {  // levels without a sampled row inside a bound's range are passed without a load
+        while (t0[s] >= 0 && lcx_first_sample(a0[s], 4 * t0[s]) >= b0[s]) t0[s]--;
+        while (t1[s] >= 0 && lcx_first_sample(a1[s], 4 * t1[s]) >= b1[s]) t1[s]--;
+        if (t0[s] < 0 && t1[s] < 0) state[s] = LQ_DONE;
         else {
-          shared = t0 == t1 && a0 == a1 && b0 == b1;
-          bound = shared ? 2 : (t0 >= t1 ? 0 : 1);
-          tl = bound == 1 ? t1 : t0;
-          nb = (lcx_first_sample(bound == 1 ? a1 : a0, 4 * tl) >> (4 * tl)) & ~15ull;
-          node = (tl == 0 ? ix.lcx_key : ix.lcx_inner + ix.lcx_off[tl]) + nb;
-          want_node = true;
+          shared[s] = t0[s] == t1[s] && a0[s] == a1[s] && b0[s] == b1[s];
+          if (t0[s] >= 0) nb0[s] = (uint32_t)((lcx_first_sample(a0[s], 4 * t0[s]) >> (4 * t0[s])) & ~15ull);
+          if (t1[s] >= 0) nb1[s] = (uint32_t)((lcx_first_sample(a1[s], 4 * t1[s]) >> (4 * t1[s])) & ~15ull);
+          want_node[s] = true;
         }
       }
-      // ---- DONE: what the search found decides what comes next (no load in this iteration)
-      bool settle = false, fallback = false;
-      uint64_t out_count = 0, out_rs = 0;
-      if (state == LL_DONE) {
-        if (!tail_pass && vn == 0) {  // straight from the search
-          lb = a0;
-          hits = a1 - a0;
+      if (state[s] == LQ_DONE) {  // what the search found decides what comes next
+        const uint32_t lb = a0[s], hits = a1[s] - a0[s];
+        const int i = ii[s];
+        const uint64_t rs_run = hits && hits <= 8u ? ((RS_LCX << RS_MODE_SHIFT) | (uint64_t)lb | ((uint64_t)i << 32) | ((uint64_t)((1u << hits) - 1u) << 48))
+                                                   : ((RS_PLAIN << RS_MODE_SHIFT) | 1ull);
+        if (!tail_pass[s] && vn[s] == 0) {  // straight from the search
           if (!READS || i <= LCX_CTX) {
-            if (inc && i < LCX_CTX) { tail_pass = true; vj = 0; vn = (int)inc; vmask = 0; state = LL_POS; }
-            else if (!READS || !range_start || hits <= 8u) {
-              settle = true;
-              out_count = hits;
-              out_rs = hits && hits <= 8u ? ((RS_LCX << RS_MODE_SHIFT) | (uint64_t)lb | ((uint64_t)i << 32) | ((uint64_t)((1u << hits) - 1u) << 48)) : ((RS_PLAIN << RS_MODE_SHIFT) | 1ull);
-            } else fallback = true;  // the locate pass wants the rows of a larger range
+            if (inc[s] && i < LCX_CTX) { tail_pass[s] = true; vj[s] = 0; vn[s] = (int)inc[s]; vmask[s] = 0; state[s] = LQ_POS; }
+            else if (!READS || !range_start || hits <= 8u) { settle = true; out_count = hits; out_rs = rs_run; }
+            else to_lf[s] = true;  // the locate pass wants the rows of a larger range
           } else if (hits == 0u) { settle = true; out_rs = (RS_PLAIN << RS_MODE_SHIFT) | 1ull; }
-          else if (hits <= 8u) { vj = 0; vn = (int)hits; vmask = 0; state = LL_POS; }  // compare each with the text
-          else fallback = true;
-        } else if (tail_pass) {  // the bucket's incomplete entries have been compared with the text
-          const uint32_t th = (uint32_t)__popc(vmask);
-          if (!READS || !range_start || (th == 0u && hits <= 8u)) {
-            settle = true;
-            out_count = (uint64_t)hits + th;
-            out_rs = hits && hits <= 8u ? ((RS_LCX << RS_MODE_SHIFT) | (uint64_t)lb | ((uint64_t)i << 32) | ((uint64_t)((1u << hits) - 1u) << 48)) : ((RS_PLAIN << RS_MODE_SHIFT) | 1ull);
-          } else fallback = true;
+          else if (hits <= 8u) { vj[s] = 0; vn[s] = (int)hits; vmask[s] = 0; state[s] = LQ_POS; }  // compare each with the text
+          else to_lf[s] = true;
+        } else if (tail_pass[s]) {  // the bucket's incomplete entries have been compared with the text
+          const uint32_t th = (uint32_t)__popc(vmask[s]);
+          if (!READS || !range_start || (th == 0u && hits <= 8u)) { settle = true; out_count = (uint64_t)hits + th; out_rs = rs_run; }
+          else to_lf[s] = true;
         } else {  // the candidates have been compared with the text
           settle = true;
-          out_count = (uint64_t)__popc(vmask);
-          if (vn == 1 && vmask) out_rs = (RS_SINGLE << RS_MODE_SHIFT) | ((uint64_t)vp - (uint64_t)i);
-          else out_rs = (RS_LCX << RS_MODE_SHIFT) | (uint64_t)lb | ((uint64_t)i << 32) | ((uint64_t)vmask << 48);
+          out_count = (uint64_t)__popc(vmask[s]);
+          if (vn[s] == 1 && vmask[s]) out_rs = (RS_SINGLE << RS_MODE_SHIFT) | ((uint64_t)vp[s] - (uint64_t)i);
+          else out_rs = (RS_LCX << RS_MODE_SHIFT) | (uint64_t)lb | ((uint64_t)i << 32) | ((uint64_t)vmask[s] << 48);
         }
-      }
-      // ---- issue.  (The load groups of the states share their registers: a lane is in one state.)
-      uint64_t f0 = 0, f1 = 0, f2 = 0;  // FETCH: word, entry, query index; FETCH2: length; TAILCNT: key; POS: (position, row); TXT: query words
-      ulonglong2 B[8];                  // the node pieces this lane fetches for the wave, then (SEARCH) this lane's own node
-      Text20 tx[2];                     // TXT: two text windows of 32 letters
-#pragma unroll
-      for (int j = 0; j < 8; j++) B[j] = ulonglong2{0, 0};
-      tx[0] = tx[1] = Text20{{0u, 0u, 0u, 0u, 0u}};
-      if (state == LL_FETCH) {
-        f0 = in.w[item];
-        f1 = in.range[item];
-        f2 = in.q[item];
-      }
-      if (READS && RAGGED && state == LL_FETCH2) f2 = lens[q];
-      if (state == LL_TAILCNT) f0 = ix.lcx_key[sp + cnt - 1u];
-      if (state == LL_POS) f0 = ix.lcx_rowpos[(tail_pass ? sp + (cnt - inc) : lb) + (uint32_t)vj];
-      if (state == LL_TXT) {
-        const uint64_t g = (uint64_t)vp - (uint64_t)i;
-#pragma unroll
-        for (int c = 0; c < 2; c++) {
-          const int ch = vc + c;
-          if (32 * ch < i) {
-            tx[c] = *reinterpret_cast<const Text20*>(text4 + ((g + 32ull * ch) >> 3));
-            const uint64_t qword = READS ? queries[(uint64_t)q * W + ch] : w;
-            if (c == 0) f0 = qword; else f1 = qword;
+        if (settle) {
+          if (l == 0) {
+            counts[q[s]] = out_count;
+            if (READS && range_start) range_start[q[s]] = out_rs;
           }
+          state[s] = LQ_IDLE;  // (takes its next item in the next iteration)
         }
       }
-      const uint64_t wm = __ballot(want_node);
-      if (wm) {  // round r: the eight lanes 8j..8j+7 fetch the node of lane 8r + j, one 16-B piece each
-        const unsigned long long mine = reinterpret_cast<unsigned long long>(node);
+    }
+    // ---- issue
 #pragma unroll
-        for (int r = 0; r < 8; r++) {
-          const int src = 8 * r + (lane >> 3);
-          const unsigned long long p = __shfl(mine, src, 64);
-          if ((wm >> src) & 1ull) B[r] = reinterpret_cast<const ulonglong2*>(p)[lane & 7];
+    for (int s = 0; s < SLOTS; s++) {
+      if (READS && RAGGED && state[s] == LQ_FETCH2) K[s][0] = lens[q[s]];
+      if (state[s] == LQ_TAILCNT) K[s][0] = ix.lcx_key[sp[s] + cnt[s] - 1u];
+      if (state[s] == LQ_POS) K[s][0] = ix.lcx_rowpos[(tail_pass[s] ? sp[s] + (cnt[s] - inc[s]) : a0[s]) + (uint32_t)vj[s]];
+      if (want_node[s]) {
+        if (t0[s] >= 0) {
+          const ulonglong2* p = reinterpret_cast<const ulonglong2*>((t0[s] == 0 ? ix.lcx_key : ix.lcx_inner + ix.lcx_off[t0[s]]) + (uint64_t)nb0[s] + 4 * l);
+          const ulonglong2 x = p[0], y = p[1];
+          K[s][0] = x.x; K[s][1] = x.y; K[s][2] = y.x; K[s][3] = y.y;
+        }
+        if (t1[s] >= 0 && !shared[s]) {
+          const ulonglong2* p = reinterpret_cast<const ulonglong2*>((t1[s] == 0 ? ix.lcx_key : ix.lcx_inner + ix.lcx_off[t1[s]]) + (uint64_t)nb1[s] + 4 * l);
+          const ulonglong2 x = p[0], y = p[1];
+          K[s][4] = x.x; K[s][5] = x.y; K[s][6] = y.x; K[s][7] = y.y;
         }
       }
-      asm volatile("" : "+v"(tx[0].w[0]), "+v"(tx[0].w[1]), "+v"(tx[0].w[2]), "+v"(tx[0].w[3]), "+v"(tx[0].w[4]),
-                        "+v"(tx[1].w[0]), "+v"(tx[1].w[1]), "+v"(tx[1].w[2]), "+v"(tx[1].w[3]), "+v"(tx[1].w[4]));
-      asm volatile("" : "+v"(f0), "+v"(f1), "+v"(f2), "+v"(B[0].x), "+v"(B[0].y), "+v"(B[1].x), "+v"(B[1].y), "+v"(B[2].x), "+v"(B[2].y),
-                   "+v"(B[3].x), "+v"(B[3].y), "+v"(B[4].x), "+v"(B[4].y), "+v"(B[5].x), "+v"(B[5].y), "+v"(B[6].x), "+v"(B[6].y),
-                   "+v"(B[7].x), "+v"(B[7].y));
-      if (wm) {  // pieces -> tile, then every searching lane picks up its own node
-#pragma unroll
-        for (int r = 0; r < 8; r++) s_blk[wv_id][(8 * r + (lane >> 3)) * ROW + (lane & 7)] = B[r];
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        if (want_node) {
-#pragma unroll
-          for (int j = 0; j < 8; j++) B[j] = s_blk[wv_id][lane * ROW + j];
+      if (state[s] == LQ_TXT) {  // lane l: letters [128 vc + 32 l, + 32) of the i letters in front of the candidate
+        const int j0 = 128 * vc[s] + 32 * l;
+        if (j0 < ii[s]) {
+          const uint64_t g = (uint64_t)vp[s] - (uint64_t)ii[s] + (uint64_t)j0;
+          const Text20 t = *reinterpret_cast<const Text20*>(text4 + (g >> 3));
+          K[s][0] = (uint64_t)t.w[0] | ((uint64_t)t.w[1] << 32);
+          K[s][1] = (uint64_t)t.w[2] | ((uint64_t)t.w[3] << 32);
+          K[s][2] = t.w[4];
+          const int wi = 4 * vc[s] + l;
+          K[s][3] = READS ? (wi < W ? queries[(uint64_t)q[s] * W + wi] : 0ull) : w[s];
         }
-        __builtin_amdgcn_wave_barrier();
       }
-      // ---- consume
-      bool to_lf = false;  // this lane's survivor goes to the LF list
-      if (settle) {
-        counts[q] = out_count;
-        if (READS && range_start) range_start[q] = out_rs;
-        state = LL_IDLE;
-      } else if (fallback) {
-        to_lf = true;
-      } else if (state == LL_FETCH) {
-        w = f0;
-        q = (uint32_t)f2;
-        const uint64_t f_rg = f1;
-        sp = (uint32_t)f_rg;
-        const uint32_t cf = (uint32_t)(f_rg >> 32);
-        cnt = cf & SEED_CNT_SAT;
-        flags = cf & (SEED_LCX_TAIL | SEED_LCX_NONE);
-        inc = 0;
-        vn = 0;
-        tail_pass = false;
-        i = L - k;
+    }
+#pragma unroll
+    for (int s = 0; s < SLOTS; s++)
+      asm volatile("" : "+v"(K[s][0]), "+v"(K[s][1]), "+v"(K[s][2]), "+v"(K[s][3]), "+v"(K[s][4]), "+v"(K[s][5]), "+v"(K[s][6]), "+v"(K[s][7]));
+    // ---- consume
+#pragma unroll
+    for (int s = 0; s < SLOTS; s++) {
+      const int i = ii[s];
+      const int m = i < LCX_CTX ? i : LCX_CTX;
+      const uint64_t qhi = m >= 32 ? qlo[s] : qlo[s] | ((1ull << (64 - 2 * (m > 0 ? m : 1))) - 1);
+      if (to_lf[s]) {
+        // (appended below)
+      } else if (state[s] == LQ_FETCH) {
+        if (!READS || RAGGED) w[s] = K[s][0];  // (reads: the context word is used up by the thresholds, but for the ragged pass, which still waits for its length)
+        q[s] = (uint32_t)K[s][2];
+        const uint64_t rg = K[s][1];
+        sp[s] = (uint32_t)rg;
+        const uint32_t cf = (uint32_t)(rg >> 32);
+        cnt[s] = cf & SEED_CNT_SAT;
+        flags[s] = cf & (SEED_LCX_TAIL | SEED_LCX_NONE);
+        inc[s] = 0;
+        vn[s] = 0;
+        tail_pass[s] = false;
+        ii[s] = L - k;
         // what only LF steps can do: saturated / uncovered buckets, entries the probe pass did not read, nothing left of the window
-        const bool lf = f_rg == ~0ull || cnt == SEED_CNT_SAT || cnt < 2u || (flags & SEED_LCX_NONE) || i <= 0 || i >= 65536;
-        if (lf && !(READS && RAGGED)) to_lf = true;
-        else if (READS && RAGGED) state = LL_FETCH2;
+        const bool lf = rg == ~0ull || cnt[s] == SEED_CNT_SAT || cnt[s] < 2u || (flags[s] & SEED_LCX_NONE) || ii[s] <= 0 || ii[s] >= 65536;
+        if (lf && !(READS && RAGGED)) to_lf[s] = true;
+        else if (READS && RAGGED) state[s] = LQ_FETCH2;
         else {
-          lcx_thresholds(w, i < LCX_CTX ? i : LCX_CTX, &qlo, &qhi);
-          if (flags & SEED_LCX_TAIL) state = LL_TAILCNT;
-          else { a0 = a1 = sp; b0 = b1 = sp + cnt; t0 = t1 = lcx_top_level(sp, cnt); state = LL_SEARCH; }
+          { uint64_t hi_unused; lcx_thresholds(READS ? K[s][0] : w[s], ii[s] < LCX_CTX ? ii[s] : LCX_CTX, &qlo[s], &hi_unused); }
+          if (flags[s] & SEED_LCX_TAIL) state[s] = LQ_TAILCNT;
+          else { a0[s] = a1[s] = sp[s]; b0[s] = b1[s] = sp[s] + cnt[s]; t0[s] = t1[s] = lcx_top_level(sp[s], cnt[s]); state[s] = LQ_SEARCH; }
         }
-      } else if (READS && RAGGED && state == LL_FETCH2) {
-        i = (int)(uint32_t)f2 - k;
-        const bool lf = cnt == SEED_CNT_SAT || cnt < 2u || (flags & SEED_LCX_NONE) || i <= 0 || i >= 65536 || sp == 0xFFFFFFFFu;
-        if (lf) to_lf = true;
+      } else if (READS && RAGGED && state[s] == LQ_FETCH2) {
+        ii[s] = (int)(uint32_t)K[s][0] - k;
+        const bool lf = cnt[s] == SEED_CNT_SAT || cnt[s] < 2u || (flags[s] & SEED_LCX_NONE) || ii[s] <= 0 || ii[s] >= 65536;
+        if (lf) to_lf[s] = true;
         else {
-          lcx_thresholds(w, i < LCX_CTX ? i : LCX_CTX, &qlo, &qhi);
-          if (flags & SEED_LCX_TAIL) state = LL_TAILCNT;
-          else { a0 = a1 = sp; b0 = b1 = sp + cnt; t0 = t1 = lcx_top_level(sp, cnt); state = LL_SEARCH; }
+          { uint64_t hi_unused; lcx_thresholds(w[s], ii[s] < LCX_CTX ? ii[s] : LCX_CTX, &qlo[s], &hi_unused); }
+          if (flags[s] & SEED_LCX_TAIL) state[s] = LQ_TAILCNT;
+          else { a0[s] = a1[s] = sp[s]; b0[s] = b1[s] = sp[s] + cnt[s]; t0[s] = t1[s] = lcx_top_level(sp[s], cnt[s]); state[s] = LQ_SEARCH; }
         }
-      } else if (state == LL_TAILCNT) {
-        inc = (uint32_t)f0;
+      } else if (state[s] == LQ_TAILCNT) {
+        inc[s] = (uint32_t)K[s][0];
         if (TALLY) t_nodes++;
-        if (i < LCX_CTX && inc > (uint32_t)LCX_TAIL_MAX) to_lf = true;  // too many incomplete entries to check one by one
+        if (i < LCX_CTX && inc[s] > (uint32_t)LCX_TAIL_MAX) to_lf[s] = true;  // too many incomplete entries to check one by one
         else {
-          const uint32_t nc = cnt - inc;
-          a0 = a1 = sp; b0 = b1 = sp + nc;
-          t0 = t1 = nc ? lcx_top_level(sp, nc) : -1;
-          state = LL_SEARCH;
+          const uint32_t nc = cnt[s] - inc[s];
+          a0[s] = a1[s] = sp[s]; b0[s] = b1[s] = sp[s] + nc;
+          t0[s] = t1[s] = nc ? lcx_top_level(sp[s], nc) : -1;
+          state[s] = LQ_SEARCH;
         }
-      } else if (want_node) {  // one node of level tl: the keys of rows (nb + u) << 4 tl
-        const int s = 4 * tl;
-        uint32_t c0 = 0, c1 = 0;
+      } else if (want_node[s]) {  // lane l holds keys 4 l .. 4 l + 3 of each node: rows (nb + 4 l + u) << 4 t
+        const bool do0 = t0[s] >= 0, do1 = t1[s] >= 0;
+        const int sh0 = 4 * (do0 ? t0[s] : 0), sh1 = 4 * (do1 ? t1[s] : 0);
+        uint32_t c = 0;
 #pragma unroll
-        for (int u = 0; u < 16; u++) {
-          const uint64_t key = (u & 1) ? B[u >> 1].y : B[u >> 1].x;
-          const uint64_t row = (nb + (uint64_t)u) << s;
-          if (bound != 1) c0 += (row >= a0 && row < b0 && key < qlo) ? 1u : 0u;
-          if (bound != 0) c1 += (row >= a1 && row < b1 && key <= qhi) ? 1u : 0u;
+        for (int u = 0; u < 4; u++) {
+          const uint64_t row0 = ((uint64_t)nb0[s] + (uint64_t)(4 * l + u)) << sh0, row1 = ((uint64_t)nb1[s] + (uint64_t)(4 * l + u)) << sh1;
+          const uint64_t k1 = shared[s] ? K[s][u] : K[s][4 + u];
+          if (do0) c += (row0 >= a0[s] && row0 < b0[s] && K[s][u] < qlo[s]) ? 1u : 0u;
+          if (do1) c += (row1 >= a1[s] && row1 < b1[s] && k1 <= qhi) ? 0x100u : 0u;
         }
-        if (TALLY) t_nodes++;
-        if (bound != 1) {
-          const uint64_t f = lcx_first_sample(a0, s), nbnd = f + ((uint64_t)c0 << s);
-          b0 = nbnd < b0 ? (uint32_t)nbnd : b0;
-          if (c0) a0 = (uint32_t)(f + ((uint64_t)(c0 - 1) << s) + 1);
-          t0--;
+        c = quad_sum(c);
+        if (TALLY) t_nodes += do0 && do1 && !shared[s] ? 2u : 1u;
+        if (do0) {
+          const uint32_t c0 = c & 0xffu;
+          const uint64_t f = lcx_first_sample(a0[s], sh0), nbnd = f + ((uint64_t)c0 << sh0);
+          b0[s] = nbnd < b0[s] ? (uint32_t)nbnd : b0[s];
+          if (c0) a0[s] = (uint32_t)(f + ((uint64_t)(c0 - 1) << sh0) + 1);
+          t0[s]--;
         }
-        if (bound != 0) {
-          const uint64_t f = lcx_first_sample(a1, s), nbnd = f + ((uint64_t)c1 << s);
-          b1 = nbnd < b1 ? (uint32_t)nbnd : b1;
-          if (c1) a1 = (uint32_t)(f + ((uint64_t)(c1 - 1) << s) + 1);
-          t1--;
+        if (do1) {
+          const uint32_t c1 = c >> 8;
+          const uint64_t f = lcx_first_sample(a1[s], sh1), nbnd = f + ((uint64_t)c1 << sh1);
+          b1[s] = nbnd < b1[s] ? (uint32_t)nbnd : b1[s];
+          if (c1) a1[s] = (uint32_t)(f + ((uint64_t)(c1 - 1) << sh1) + 1);
+          t1[s]--;
         }
-      } else if (state == LL_POS) {
-        vp = (uint32_t)f0;
+      } else if (state[s] == LQ_POS) {
+        vp[s] = (uint32_t)K[s][0];
         if (TALLY) t_rp++;
-        if (vp >= (uint32_t)i) { state = LL_TXT; vc = 0; }
-        else { vj++; if (vj >= vn) state = LL_DONE; }  // the suffix starts too close to the text's beginning
-      } else if (state == LL_TXT) {
+        if (vp[s] >= (uint32_t)i) { state[s] = LQ_TXT; vc[s] = 0; }
+        else { vj[s]++; if (vj[s] >= vn[s]) state[s] = LQ_DONE; }  // the suffix starts too close to the text's beginning
+      } else if (state[s] == LQ_TXT) {
         uint32_t bad = 0;
-        const uint64_t g = (uint64_t)vp - (uint64_t)i;
-#pragma unroll
-        for (int c = 0; c < 2; c++) {
-          const int ch = vc + c, m = i - 32 * ch;
-          if (m > 0) {
-            TextWin tw;
-            tw.t = tx[c];
-            tw.m = m > 32 ? 32 : m;
-            tw.sh = 4 * (int)((g + 32ull * ch) & 7);
-            bad |= text_window_differs(tw, c == 0 ? f0 : f1);
-          }
+        const int j0 = 128 * vc[s] + 32 * l;
+        if (j0 < i) {
+          TextWin tw;
+          tw.t = Text20{{(uint32_t)K[s][0], (uint32_t)(K[s][0] >> 32), (uint32_t)K[s][1], (uint32_t)(K[s][1] >> 32), (uint32_t)K[s][2]}};
+          tw.m = i - j0 > 32 ? 32 : i - j0;
+          tw.sh = 4 * (int)(((uint64_t)vp[s] - (uint64_t)i + (uint64_t)j0) & 7);
+          bad = text_window_differs(tw, K[s][3]);
         }
+        bad = quad_sum(bad);
         if (TALLY) t_txt++;
-        if (!bad && 32 * (vc + 2) < i) vc += 2;  // more of the read to compare
+        if (!bad && 128 * (vc[s] + 1) < i) vc[s]++;  // more of the read to compare
         else {
-          if (!bad) vmask |= 1u << vj;
-          vj++;
-          state = vj >= vn ? LL_DONE : LL_POS;
+          if (!bad) vmask[s] |= 1u << vj[s];
+          vj[s]++;
+          state[s] = vj[s] >= vn[s] ? LQ_DONE : LQ_POS;
         }
       }
-      const uint64_t fm = __ballot(to_lf);
-      if (fm) {  // one device-wide list (out.count[0] its length), one atomic per wave
-        unsigned int slot0 = 0;
-        if (lane == 0) slot0 = atomicAdd(out.count, (unsigned int)__popcll(fm));
-        slot0 = __shfl(slot0, 0, 64);
-        if (to_lf) {
-          const uint64_t slot = slot0 + (uint64_t)__popcll(fm & lane_lt);
-          out.q[slot] = q;
-          if (!READS) { out.w[slot] = w; out.range[slot] = (uint64_t)sp | ((uint64_t)(cnt | flags | SEED_LCX_NONE) << 32); }
-          state = LL_IDLE;
+      const uint64_t fm = __ballot(to_lf[s] && l == 0);
+      if (fm) {  // the device-wide LF list: the wave appends to a chunk of its own and reserves the next one with ONE atomic
+        const uint32_t nf = (uint32_t)__popcll(fm);
+        if (lf_used + nf > (uint32_t)LCX_LF_CHUNK) {  // (what is left of the old chunk stays empty: q = ~0, skipped by the LF kernels)
+          for (uint32_t h = lf_used + (uint32_t)lane; h < (uint32_t)LCX_LF_CHUNK; h += 64) out.q[lf_base + h] = 0xFFFFFFFFu;
+          unsigned int b = 0;
+          if (lane == 0) b = atomicAdd(out.count, (unsigned int)LCX_LF_CHUNK);
+          lf_base = __shfl(b, 0, 64);
+          lf_used = 0;
+        }
+        const uint32_t slot0 = lf_base + lf_used;
+        lf_used += nf;
+        if (to_lf[s]) {
+          const uint64_t slot = slot0 + (uint64_t)__popcll(fm & leader_lt);
+          if (l == 0) {
+            out.q[slot] = q[s];
+            if (!READS) { out.w[slot] = w[s]; out.range[slot] = (uint64_t)sp[s] | ((uint64_t)(cnt[s] | flags[s] | SEED_LCX_NONE) << 32); }
+          }
+          state[s] = LQ_IDLE;
         }
       }
     }
   }
-  if (TALLY && tally && (t_nodes | t_rp | t_txt)) {
-    atomicAdd(&tally[6], t_nodes);
-    atomicAdd(&tally[7], t_rp);
-    atomicAdd(&tally[4], t_txt);
+  if (lf_used < (uint32_t)LCX_LF_CHUNK)  // the rest of the wave's last chunk
+    for (uint32_t h = lf_used + (uint32_t)lane; h < (uint32_t)LCX_LF_CHUNK; h += 64) out.q[lf_base + h] = 0xFFFFFFFFu;
+  if (TALLY && tally && l == 0 && (t_nodes | t_rp | t_txt)) {
+    atomicAdd(&tally[6], (unsigned long long)t_nodes);
+    atomicAdd(&tally[7], (unsigned long long)t_rp);
+    atomicAdd(&tally[4], (unsigned long long)t_txt);
   }
+}
+
+// One search per quad (SLOTS = 1: 84 registers, 5 waves per SIMD); two per quad were measured as well -- 146 registers and 3 waves
+// per SIMD, or 128 with spills: 12.4 / 13.3 ms against 9.9 ms for the count phase of 20 M 101-bp reads.  Packed k-mers keep
+// count_nt2_resume_kernel (it searches the index with the same quad code): their survivors are numerous and need nothing but
+// the search, and there this kernel's fewer resident quads cost more than its pooling gains (1.9 against 1.34 ms per 10 M
+// k-mers from the repeat-rich text).
+template <bool RAGGED>
+__global__ __launch_bounds__(256) void lcx_quad_reads_kernel(DevIndex ix, const uint64_t* __restrict__ queries, int L, uint64_t* __restrict__ counts,
+                                                             uint64_t* __restrict__ range_start, Nt2Survivors in, Nt2Survivors out, uint32_t nlists,
+                                                             const uint32_t* __restrict__ lens) {
+  lcx_quad_body<true, RAGGED, false, 1>(ix, queries, L, counts, range_start, in, out, nlists, lens, nullptr);
 }
 
 }  // namespace awry

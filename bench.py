@@ -1036,6 +1036,7 @@ def main():
         if not pmc and default_config:
             pmc = committed_traffic()
         result["pmc_phases"] = {k: {kk: vv for kk, vv in v.items() if kk != "kernels"} for k, v in pmc.items()}
+        result["phase_ids"] = {k: v["id"] for k, v in ctx.phases.items()}  # the marker grid sizes of the device-resident legs, in run order
         attach_traffic(result["roofline"], kernel_ms, pmc, "headline")
         if "variants" in result:
             v = result["variants"]

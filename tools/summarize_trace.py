@@ -39,12 +39,15 @@ for r in rows:
         continue
     per.setdefault(cur, defaultdict(list))[short(n)[:100]].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
 out["per_phase_kernel_avg_us"] = {p: {k: {"calls": len(v), "avg_us": sum(v) / len(v), "min_us": min(v)} for k, v in ks.items()
-                                      if any(t in k for t in ("count_", "locate", "localise", "scan_", "pack_"))} for p, ks in per.items()}
+                                      if any(t in k for t in ("count_", "locate", "localise", "scan_", "pack_", "lcx_"))} for p, ks in per.items()}
 try:
     b = json.load(open(bench_json))
     out["bench_line_of_this_run"] = {"value": b["value"], "ms_per_step": b["ms_per_step"], "roofline_kernel": b["roofline"]["kernel"],
                                      "roofline_kernel_ms_hip_events": b["roofline"]["kernel_ms"]}
-    out["phase_order"] = "phase ids follow bench.py's order: unseeded, present, present_lf, ascii_pack_count, ascii_one_call, locate_count_lf, locate_scan, locate_walk, locate_dense, locate_count_sv, locate_sv, amino_random, amino_offsets_random, amino_present, amino_offsets_present"
+    ids = b.get("phase_ids", {})
+    out["phases"] = {"phase_%d" % v: k for k, v in sorted(ids.items(), key=lambda kv: kv[1])}
+    if ids:
+        out["per_phase_kernel_avg_us"] = {(out["phases"].get(p, p) if p.startswith("phase_") else p): v for p, v in out["per_phase_kernel_avg_us"].items()}
 except (OSError, ValueError, KeyError):
     pass
 print(json.dumps(out, indent=1))

@@ -2392,12 +2392,14 @@ void prewarm_host_paths(Replica& r) {
     for (int li = 0; li < Replica::NLANES; li++) {
       PackedLane& ln = r.lanes[li];
       hipStream_t s = r.lane_stream[li];
-      memset(ln.h_words.p, 0, 64 * 8);
-      HIP_CHECK(hipMemcpyAsync(ln.words.p, ln.h_words.p, 64 * 8, hipMemcpyHostToDevice, s));
+      memset(ln.h_words.p, 0, cap * 8);  // (a whole chunk each way: large pinned copies take the copy engines, small ones do not)
+      HIP_CHECK(hipMemcpyAsync(ln.words.p, ln.h_words.p, cap * 8, hipMemcpyHostToDevice, s));
       launch_count_nt2(r, ln.words.p, 64, r.seed_k > 0 && r.seed_k < 31 ? r.seed_k + 1 : 31, ln.counts.p, true, s, nullptr);
       launch_count_nt2_long(r, ln.words.p, 16, 101, ln.counts.p, nullptr, true, s, nullptr);
-      hipLaunchKernelGGL(narrow_counts_kernel, dim3(1), dim3(256), 0, s, ln.counts.p, ln.counts32.p, (uint64_t)64);
-      HIP_CHECK(hipMemcpyAsync(ln.h_counts32.p, ln.counts32.p, 64 * 4, hipMemcpyDeviceToHost, s));
+      hipLaunchKernelGGL(narrow_counts_kernel, dim3(grid_for(r, cap, 1024)), dim3(256), 0, s, ln.counts.p, ln.counts32.p, cap);
+      HIP_CHECK(hipMemcpyAsync(ln.h_counts32.p, ln.counts32.p, cap * 4, hipMemcpyDeviceToHost, s));
+      HIP_CHECK(hipEventRecord(ln.done, s));
+      HIP_CHECK(hipEventSynchronize(ln.done));
       HIP_CHECK(hipStreamSynchronize(s));
     }
   // pinned result arrays of one typical locate call (offsets, positions, (record, offset) pairs of a few million hits):

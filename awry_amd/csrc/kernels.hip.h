@@ -1447,19 +1447,26 @@ __device__ __forceinline__ void resume_block_list(const DevIndex& ix, const Nt2S
   // entry vj, 6 = compare it with the text
   int mode = 0, vj = 0;
   uint32_t vhits = 0, vp = 0;
-  LcxQ lq{0, 0, 0, 0, -1};
-  uint64_t qlo = 0, qhi = 0;
-  uint32_t b_cnt = 0, b_inc = 0;  // rows / incomplete rows of the bucket being searched
+  // The search of a bucket's keys keeps its state in the variables the LF modes do not use meanwhile -- this kernel runs
+  // as many waves as its registers allow, and a search is a chain of dependent loads: lower bound [vp, vhits), upper bound
+  // [ub_a, ub_b), level vj, incomplete rows of the bucket steps_done; ep stays the bucket's last row.
+  uint32_t ub_a = 0, ub_b = 0;
+  const LcxRefs lq{vp, vhits, ub_a, ub_b, vj};
   uint32_t t_step = 0, t_blk = 0, t_vsa = 0, t_vtxt = 0, t_lcx = 0, t_rp = 0;
+  // the next record of this quad's walk is asked for while the current one is searched (one dependent load less per survivor)
+  uint64_t nx_w = 0, nx_rg = 0;
+  uint32_t nx_q = 0;
+  if (have) { nx_w = sv.w[region + r]; nx_rg = sv.range[region + r]; nx_q = sv.q[region + r]; }
   while (__any(have)) {
     if (have) {
       bool finished = false;
       uint64_t out_count = 0;
       if (mode == 0) {
         if (fresh) {  // the record replaces the seed probe; the first step follows in the same iteration
-          w = sv.w[region + r];
-          const uint64_t rg = sv.range[region + r];
-          qidx = sv.q[region + r];
+          w = nx_w;
+          const uint64_t rg = nx_rg;
+          qidx = nx_q;
+          if (r + r_stride < ns) { nx_w = sv.w[region + r + r_stride]; nx_rg = sv.range[region + r + r_stride]; nx_q = sv.q[region + r + r_stride]; }
           const uint32_t cf = (uint32_t)(rg >> 32), cnt = cf & SEED_CNT_SAT;
           steps_done = 0;
           fresh = false;
@@ -1475,12 +1482,9 @@ __device__ __forceinline__ void resume_block_list(const DevIndex& ix, const Nt2S
             ep = sp + cnt - 1u;
             i = L - k;
             if (lcx && cnt >= 2u && !(cf & SEED_LCX_NONE) && i > 0) {  // the bucket's keys tell its rows apart: no LF step
-              b_cnt = cnt;
-              b_inc = 0;
-              lcx_thresholds(w, i, &qlo, &qhi);
-              vhits = 0;
+              steps_done = 0;  // (incomplete rows of the bucket)
               if (cf & SEED_LCX_TAIL) mode = 3;
-              else { lcx_begin(lq, sp, cnt); mode = 4; }
+              else { vp = ub_a = sp; vhits = ub_b = sp + cnt; vj = lcx_top_level(sp, cnt); mode = 4; }
             }
           }
         }
@@ -1515,20 +1519,27 @@ __device__ __forceinline__ void resume_block_list(const DevIndex& ix, const Nt2S
         vj++;
         mode = 1;
       } else if (mode == 3) {  // the key slot of the bucket's last row holds the number of incomplete entries
-        b_inc = (uint32_t)ix.lcx_key[sp + b_cnt - 1u];
+        const uint32_t inc = (uint32_t)ix.lcx_key[ep];
         if (TALLY) t_lcx++;
-        if (b_inc > (uint32_t)LCX_TAIL_MAX) { mode = 0; b_cnt = 0; }  // (too many to check one by one: LF steps after all)
-        else { lcx_begin(lq, sp, b_cnt - b_inc); mode = 4; }
+        if (inc > (uint32_t)LCX_TAIL_MAX) { mode = 0; steps_done = 0; }  // (too many to check one by one: LF steps after all)
+        else {
+          const uint32_t nc = ep - sp + 1u - inc;
+          steps_done = (int)inc;
+          vp = ub_a = sp; vhits = ub_b = sp + nc; vj = nc ? lcx_top_level(sp, nc) : -1;
+          mode = 4;
+        }
       } else if (mode == 4) {
+        uint64_t qlo, qhi;
+        lcx_thresholds(w, i, &qlo, &qhi);
         const int lines = lcx_quad_step(ix, lq, qlo, qhi, l);
         if (TALLY) t_lcx += (uint32_t)lines;
-        if (lq.t < 0) {
-          vhits = lq.a1 - lq.a0;
-          if (b_inc) { mode = 5; vj = 0; }
+        if (vj < 0) {
+          vhits = ub_a - vp;  // the run of rows the keys select
+          if (steps_done) { mode = 5; vj = 0; }
           else { finished = true; out_count = vhits; }
         }
       } else if (mode == 5) {  // incomplete entry vj: its text position
-        vp = (uint32_t)ix.lcx_rowpos[sp + (b_cnt - b_inc) + (uint32_t)vj];
+        vp = (uint32_t)ix.lcx_rowpos[ep + 1u - (uint32_t)steps_done + (uint32_t)vj];
         if (TALLY) t_rp++;
         if (vp >= (uint32_t)i) mode = 6;
         else vj++;
@@ -1540,7 +1551,7 @@ __device__ __forceinline__ void resume_block_list(const DevIndex& ix, const Nt2S
         mode = 5;
       }
       if (VERIFY && mode == 1 && vj > (int)(ep - sp)) { finished = true; out_count = vhits; }
-      if (mode == 5 && vj >= (int)b_inc) { finished = true; out_count = vhits; }
+      if (mode == 5 && vj >= steps_done) { finished = true; out_count = vhits; }
       if (finished) {
         if (l == 0 && qidx != 0xFFFFFFFFu) counts[qidx] = out_count;
         r += r_stride;

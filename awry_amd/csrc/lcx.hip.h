@@ -73,7 +73,8 @@ __device__ __forceinline__ uint64_t lcx_first_sample(uint32_t a, int s) { return
 
 // One level for both bounds (quad-cooperative: lane l of the quad holds 4 of a node's 16 keys).  Levels at which
 // neither range holds a sampled row are passed without a load.  Returns the number of lines it asked for (0, 1 or 2).
-__device__ __forceinline__ int lcx_quad_step(const DevIndex& ix, LcxQ& q, uint64_t qlo, uint64_t qhi, int l) {
+struct LcxRefs { uint32_t &a0, &b0, &a1, &b1; int& t; };  // the same state held in the caller's own variables
+__device__ __forceinline__ int lcx_quad_step(const DevIndex& ix, LcxRefs q, uint64_t qlo, uint64_t qhi, int l) {
   while (q.t >= 0) {
     const int s = 4 * q.t;
     const uint64_t f0 = lcx_first_sample(q.a0, s), f1 = lcx_first_sample(q.a1, s);
@@ -110,6 +111,9 @@ __device__ __forceinline__ int lcx_quad_step(const DevIndex& ix, LcxQ& q, uint64
     return same || !(has0 && has1) ? 1 : 2;
   }
   return 0;
+}
+__device__ __forceinline__ int lcx_quad_step(const DevIndex& ix, LcxQ& q, uint64_t qlo, uint64_t qhi, int l) {
+  return lcx_quad_step(ix, LcxRefs{q.a0, q.b0, q.a1, q.b1, q.t}, qlo, qhi, l);
 }
 
 // the thresholds of a search for the m = min(i, 32) letters nearest the seed window: ctx = those letters packed like a

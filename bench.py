@@ -306,7 +306,7 @@ def run_variants(ctx, ix, text_d, batches, nq, L, counts, tally, oi, cores, abla
             ts.append(time.perf_counter() - tp)
         return ts
 
-    h_counts = np.zeros(na, dtype=np.uint64)  # caller-owned counts_out, reused from call to call
+    h_counts = np.ones(na, dtype=np.uint64)  # caller-owned counts_out, reused from call to call (written once: its pages exist)
     ts = host_times(lambda: ix.parallel_count_csr(h_q, h_off, h_counts))
     first_call, med = ts[0], sorted(ts[1:])[len(ts[1:]) // 2]
     assert np.array_equal(h_counts, want_h)
@@ -398,6 +398,7 @@ def locate_benchmark(ctx, ix, text_d, n_reads, read_len, oi=None, cores=1):
             "algorithmic_GBs": alg / (ms * 1e-3) / 1e9, "frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
             "end_to_end_reads_per_s_device_resident": n_reads / ((ms_count + ms_scan + ms) * 1e-3)}
     # seed-and-verify: dense SA + 4-bit text resident; the rest of a read is compared with the text, not LF-stepped
+    torch.cuda.empty_cache()  # (the library sizes its accelerators from the HBM that is free: hand back what torch only caches)
     tv = time.time()
     ix.set_verify(2)
     build_s = time.time() - tv

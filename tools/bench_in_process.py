@@ -65,6 +65,14 @@ def main(args):
             ts.append(time.perf_counter() - tp)
         return sorted(ts)[len(ts) // 2], sum(ts)
 
+    # the ceiling the host sets: the packer alone (ASCII -> 2-bit words on the worker pool, no GPU, no result array) and the
+    # widening copy of the counts, both at this process's CPU quota -- what N replicas share however many GPUs serve them
+    import ctypes as C
+    lib = awry_amd.load_library()
+    pw = np.zeros(total, dtype=np.uint64)
+    pbad, pnb = np.zeros(total, dtype=np.uint32), C.c_uint64()
+    med_pack, _ = timed(lambda: lib.awry_host_pack_nt2(qb.ctypes.data, None, total, L, pw.ctypes.data_as(C.POINTER(C.c_uint64)), None,
+                                                       pbad.ctypes.data_as(C.POINTER(C.c_uint32)), C.byref(pnb)), 1, 5)
     med, tot = timed(lambda: ix.parallel_count_csr(qb, qo, out), W, K)
     counts_ascii = out.copy()
     med_p, _ = timed(lambda: ix.parallel_count_packed(words, L, out), 1, max(3, K // 4))
@@ -129,6 +137,10 @@ def main(args):
                    "sharding": "one process; index replicated per GPU by awry_set_devices; contiguous query shards, one host thread + pinned lanes "
                                "per replica, shared packer pool; no collective"},
         "caller_packed_kmers_queries_per_s": total / med_p,
+        "host_packer_alone_queries_per_s": total / med_pack,
+        "host_bound": {"packer_alone_queries_per_s": total / med_pack, "boundary_over_packer": (total / med) / (total / med_pack),
+                       "note": "the packer (read L bytes, write 8 per query) on this process's CPU quota is the ceiling of the ASCII boundary for any number "
+                               "of replicas; the replicas' shards are packed concurrently by one pool (jobs from several callers share its threads)"},
         "device_resident_queries_per_s": total * K / dt_res,
         "locate": {"reads": nr, "hits": int(hoff[-1]), "reads_per_s": nr / dt_loc, "note": "awry_locate_batch, PCIe-inclusive, best of 2 after 1 warm-up"},
         "checks": {"packed_equals_ascii": True, "sharded_equals_single_replica_on_sample": True, "device_resident_equals_host_path": True},

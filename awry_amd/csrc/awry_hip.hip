@@ -971,6 +971,12 @@ bool lcx_lanes(const Replica& r) {
   static const bool off = getenv("AWRY_LCX_POOL") && !strcmp(getenv("AWRY_LCX_POOL"), "0");
   return !off && r.dev.lcx_key != nullptr && r.dev.text4 != nullptr && r.dev.dense_ratio == 1;
 }
+// wide-row replicas: the two-phase schedule (count_nt2_wide_probe_kernel + the listed quad pass) is an alternative, not the
+// policy -- on a GRCh38-scale index forced onto 64-bit rows (k = 16, 69 GB of 16-byte entries) it runs random 31-mers at 16.7
+// against 16.5 G/s and reads from the text 10 % slower than the single strided quad kernel: without the 32-bit accelerators
+// (dense SA, text, position seeds) the entry settles too few queries for a second launch to pay.  Selected with
+// AWRY_COUNT_KERNEL=twophase / awry_debug_set_count_kernel(3).
+bool wide_two_phase(uint64_t n) { return count_kernel_override() == 3 && n < (1ull << 32); }
 // the survivor lists of a two-phase launch over n queries: `in` (all three arrays) and, with lanes, the fallback lists `out`
 void two_phase_lists(Replica& r, hipStream_t s, uint64_t n, bool lanes, Nt2Survivors* in, Nt2Survivors* out, unsigned* nblk_out) {
   Replica::SurvScratch* sc = surv_scratch(r, s);
@@ -1015,6 +1021,20 @@ void launch_count_nt2_long(Replica& r, const uint64_t* d_words, uint64_t n, int 
   if (r.wide) {  // 64-bit rows
     const bool sdw = use_seed && r.seed_k > 0 && r.dev.seed64 && (d_lens || r.seed_k <= L);
     const dim3 gw(grid_for(r, n * 4, 256)), bw(256);
+    if (sdw && wide_two_phase(n)) {  // per-lane probe pass, then the quads on what has to be stepped
+      Nt2Survivors sv, fb;
+      unsigned nblk = 0;
+      two_phase_lists(r, s, n, false, &sv, &fb, &nblk);
+      if (d_lens) {
+        hipLaunchKernelGGL((count_nt2_wide_probe_kernel<true, false>), dim3(nblk), bw, 0, s, r.dev, d_words, n, L, d_counts, d_range_start, sv, d_lens, (unsigned long long*)nullptr);
+        hipLaunchKernelGGL((count_nt2_wide_kernel<true, true, true>), dim3(nblk), bw, 0, s, r.dev, d_words, n, L, d_counts, d_range_start, d_lens, (unsigned long long*)nullptr, sv);
+      } else {
+        hipLaunchKernelGGL((count_nt2_wide_probe_kernel<false, false>), dim3(nblk), bw, 0, s, r.dev, d_words, n, L, d_counts, d_range_start, sv, d_lens, (unsigned long long*)nullptr);
+        hipLaunchKernelGGL((count_nt2_wide_kernel<true, false, true>), dim3(nblk), bw, 0, s, r.dev, d_words, n, L, d_counts, d_range_start, d_lens, (unsigned long long*)nullptr, sv);
+      }
+      HIP_CHECK(hipGetLastError());
+      return;
+    }
 #define AWRY_LAUNCH_WIDE(S, R) hipLaunchKernelGGL((count_nt2_wide_kernel<S, R>), gw, bw, 0, s, r.dev, d_words, n, L, d_counts, d_range_start, d_lens, (unsigned long long*)nullptr)
     if (d_lens) { if (sdw) AWRY_LAUNCH_WIDE(true, true); else AWRY_LAUNCH_WIDE(false, true); }
     else { if (sdw) AWRY_LAUNCH_WIDE(true, false); else AWRY_LAUNCH_WIDE(false, false); }
@@ -1073,6 +1093,16 @@ void launch_count_nt2(Replica& r, const uint64_t* d_words, uint64_t n, int L, ui
   if (r.wide) {  // 64-bit rows: one word per k-mer is the W = 1 case of the wide kernel
     const bool sdw = use_seed && r.seed_k > 0 && r.dev.seed64 && r.seed_k <= L;
     const dim3 gw(grid_for(r, n * 4, 256)), bw(256);
+    if (sdw && wide_two_phase(n)) {
+      Nt2Survivors sv, fb;
+      unsigned nblk = 0;
+      two_phase_lists(r, s, n, false, &sv, &fb, &nblk);
+      if (d_tally) hipLaunchKernelGGL((count_nt2_wide_probe_kernel<false, true>), dim3(nblk), bw, 0, s, r.dev, d_words, n, L, d_counts, (uint64_t*)nullptr, sv, (const uint32_t*)nullptr, d_tally);
+      else hipLaunchKernelGGL((count_nt2_wide_probe_kernel<false, false>), dim3(nblk), bw, 0, s, r.dev, d_words, n, L, d_counts, (uint64_t*)nullptr, sv, (const uint32_t*)nullptr, d_tally);
+      hipLaunchKernelGGL((count_nt2_wide_kernel<true, false, true>), dim3(nblk), bw, 0, s, r.dev, d_words, n, L, d_counts, (uint64_t*)nullptr, (const uint32_t*)nullptr, d_tally, sv);
+      HIP_CHECK(hipGetLastError());
+      return;
+    }
     if (sdw) hipLaunchKernelGGL((count_nt2_wide_kernel<true, false>), gw, bw, 0, s, r.dev, d_words, n, L, d_counts, (uint64_t*)nullptr, (const uint32_t*)nullptr, d_tally);
     else hipLaunchKernelGGL((count_nt2_wide_kernel<false, false>), gw, bw, 0, s, r.dev, d_words, n, L, d_counts, (uint64_t*)nullptr, (const uint32_t*)nullptr, d_tally);
     HIP_CHECK(hipGetLastError());
@@ -2459,7 +2489,7 @@ const char* awry_count_schedule(const awry_index_t* idx, int L) {
                                 "count_nt2_probe_kernel+count_nt2_resume_kernel"};
   if (!idx || idx->reps.empty()) return "";
   const Replica& r = *idx->reps[0];
-  if (r.wide) return "count_nt2_wide_kernel";
+  if (r.wide) return count_kernel_override() == 3 && r.seed_k > 0 && r.seed_k <= L ? "count_nt2_wide_probe_kernel+count_nt2_wide_kernel" : "count_nt2_wide_kernel";
   const bool seeded = r.seed_k > 0 && r.seed_k <= L;
   if (L > 32) {  // launch_count_nt2_long
     const int om = count_kernel_override();

@@ -2889,19 +2889,25 @@ __global__ __launch_bounds__(256) void seed64_finalize_kernel(DevIndex ix, SeedE
 // Packed reads / k-mers of any length on a wide-row index: W = ceil(L / 32) words per query (L <= 32: one word, the
 // k-mer layout), one query per quad, strided.  RAGGED: read q has lens[q] letters.  Counts, and (optional) the first row
 // of each range for the locate pass (RS_PLAIN words).  tally (nullable): [0] probes, [1] steps, [2] blocks ranked.
-template <bool USE_SEED, bool RAGGED>
+// LIST: the quads of block b work through the queries block b of count_nt2_wide_probe_kernel left undecided (sv.q, with
+// the probed range in sv.range / sv.w, so the table is not read again) instead of all n.
+template <bool USE_SEED, bool RAGGED, bool LIST = false>
 __global__ __launch_bounds__(256) void count_nt2_wide_kernel(DevIndex ix, const uint64_t* __restrict__ queries, uint64_t n, int L,
                                                              uint64_t* __restrict__ counts, uint64_t* __restrict__ range_start,
-                                                             const uint32_t* __restrict__ lens, unsigned long long* __restrict__ tally) {
+                                                             const uint32_t* __restrict__ lens, unsigned long long* __restrict__ tally,
+                                                             Nt2Survivors sv = Nt2Survivors{}) {
   const int l = threadIdx.x & 3;
   const uint64_t nquads = ((uint64_t)gridDim.x * blockDim.x) >> 2;
-  uint64_t q = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 2;
+  const uint64_t region = LIST ? (uint64_t)blockIdx.x * sv.cap : 0;
+  uint64_t r = threadIdx.x >> 2;  // LIST: position in the block's list
+  if (LIST) n = sv.count[blockIdx.x];
+  uint64_t q = LIST ? (r < n ? sv.q[region + r] : 0) : ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 2;
   const uint64_t* __restrict__ blocks = ix.blocks;
   const SeedEntry64* __restrict__ seed = ix.seed64;
   const int k = USE_SEED ? ix.seed_k : 1, W = (L + 31) / 32;
   const uint64_t cA = ix.prefix_sums[1], cC = ix.prefix_sums[2], cG = ix.prefix_sums[3], cN = ix.prefix_sums[4], cT = ix.prefix_sums[5],
                  cEnd = ix.prefix_sums[6];
-  bool have = q < n, fresh = true;
+  bool have = LIST ? r < n : q < n, fresh = true;
   uint64_t w = 0, sp = 1, ep = 0;
   int i = 0;
   unsigned long long t_probe = 0, t_step = 0, t_blk = 0;
@@ -2912,7 +2918,12 @@ __global__ __launch_bounds__(256) void count_nt2_wide_kernel(DevIndex ix, const 
         const int Lq = RAGGED ? (int)lens[q] : L;
         const bool seeded = USE_SEED && Lq >= k;
         const int first = seeded ? Lq - k : 0;  // letters first .. Lq-1 form the seed window (leftmost letter least significant)
-        if (seeded) {
+        const uint64_t probed = LIST ? sv.w[region + r] : 0ull;  // the entry's row count as phase 1 read it (0: it did not probe)
+        if (LIST && seeded && probed) {
+          sp = sv.range[region + r];
+          ep = sp + probed - 1ull;
+          i = first;
+        } else if (seeded) {
           const int a = first >> 5, sh = 2 * (first & 31);
           uint64_t win = qw[a] >> sh;
           if (sh && a + 1 < W) win |= qw[a + 1] << (64 - sh);
@@ -2948,8 +2959,14 @@ __global__ __launch_bounds__(256) void count_nt2_wide_kernel(DevIndex ix, const 
           counts[q] = sp > ep ? 0ull : ep - sp + 1ull;
           if (range_start) range_start[q] = (RS_PLAIN << RS_MODE_SHIFT) | sp;
         }
-        q += nquads;
-        have = q < n;
+        if (LIST) {
+          r += 64;
+          have = r < n;
+          q = have ? sv.q[region + r] : 0;
+        } else {
+          q += nquads;
+          have = q < n;
+        }
         fresh = true;
       }
     }
@@ -2959,6 +2976,102 @@ __global__ __launch_bounds__(256) void count_nt2_wide_kernel(DevIndex ix, const 
     atomicAdd(&tally[1], t_step);
     atomicAdd(&tally[2], t_blk);
   }
+}
+
+// Phase 1 of a two-phase schedule for wide-row indexes (the narrow path's count_nt2_probe_kernel / count_nt2_reads_probe_kernel
+// without the 32-bit accelerators): one query per LANE, two in flight -- coalesced query reads and count writes, 64
+// independent 16-byte seed probes per wave instruction (non-temporal).  The entry settles a query whose seed k-mer is absent,
+// a singleton whose BWT symbol is not the next letter, and a query that is its own seed window; everything else -- ranges that
+// have to be stepped, reads shorter than the seed -- is listed per block with its probed range for
+// count_nt2_wide_kernel<.., LIST>, so the LF kernel's quads only see queries that need LF steps.
+template <bool RAGGED, bool TALLY>
+__global__ __launch_bounds__(256) void count_nt2_wide_probe_kernel(DevIndex ix, const uint64_t* __restrict__ queries, uint64_t n, int L,
+                                                                   uint64_t* __restrict__ counts, uint64_t* __restrict__ range_start,
+                                                                   Nt2Survivors sv, const uint32_t* __restrict__ lens,
+                                                                   unsigned long long* __restrict__ tally) {
+  __shared__ unsigned int s_count;
+  if (threadIdx.x == 0) s_count = 0;
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const SeedEntry64* __restrict__ seed = ix.seed64;
+  const int k = ix.seed_k, W = (L + 31) / 32;
+  const uint64_t kmask = (1ull << (2 * k)) - 1;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  const uint64_t lane_lt = (1ull << lane) - 1;
+  const uint64_t region = (uint64_t)blockIdx.x * sv.cap;
+  unsigned long long t_probe = 0;
+  constexpr int NQ = 2;
+  for (uint64_t wbase = (uint64_t)blockIdx.x * blockDim.x + (threadIdx.x & ~63u); wbase < n; wbase += NQ * stride) {  // wave-uniform trip count
+    uint64_t qv[NQ], win[NQ];
+    uint32_t nc[NQ];
+    int i0[NQ];
+    bool probe[NQ];
+    ulonglong2 ev[NQ];
+#pragma unroll
+    for (int h = 0; h < NQ; h++) {
+      qv[h] = wbase + lane + (uint64_t)h * stride;
+      win[h] = 0;
+      nc[h] = 0;
+      i0[h] = 0;
+      probe[h] = false;
+      if (qv[h] < n) {
+        i0[h] = (RAGGED ? (int)lens[qv[h]] : L) - k;
+        probe[h] = i0[h] >= 0;
+        if (probe[h]) {
+          const uint64_t* qw = queries + qv[h] * W;
+          const int wa = i0[h] >> 5, wsh = 2 * (i0[h] & 31);  // seed window: letters i0 .. Lq - 1
+          win[h] = qw[wa] >> wsh;
+          if (wsh && wa + 1 < W) win[h] |= qw[wa + 1] << (64 - wsh);
+          if (i0[h] > 0) nc[h] = (uint32_t)(qw[(i0[h] - 1) >> 5] >> (2 * ((i0[h] - 1) & 31))) & 3u;  // the letter in front of it
+        }
+      }
+    }
+#pragma unroll
+    for (int h = 0; h < NQ; h++) {
+      ev[h] = ulonglong2{1ull, 0ull};
+      if (probe[h]) {
+        const unsigned long long* p = reinterpret_cast<const unsigned long long*>(seed + (win[h] & kmask));
+        ev[h].x = __builtin_nontemporal_load(p);
+        ev[h].y = __builtin_nontemporal_load(p + 1);
+        if (TALLY) t_probe++;
+      }
+    }
+#pragma unroll
+    for (int h = 0; h < NQ; h++) {
+      const bool valid = qv[h] < n;
+      const SeedEntry64 e{ev[h].x, ev[h].y};
+      const uint64_t cnt = seed64_cnt(e);
+      bool survivor = false;
+      if (valid && !probe[h]) survivor = true;  // shorter than the seed: LF steps from its last letter
+      else if (valid) {
+        uint64_t value = 0;
+        bool settled = true;
+        if (cnt == 0ull) value = 0;
+        else if (i0[h] == 0) value = cnt;
+        else if (cnt == 1ull && seed64_sym(e) != (int)(nc[h] == 3u ? 5u : nc[h] + 1u)) value = 0;  // BWT[sp] is not the next letter
+        else { settled = false; survivor = true; }
+        if (settled) {
+          counts[qv[h]] = value;
+          if (range_start) range_start[qv[h]] = (RS_PLAIN << RS_MODE_SHIFT) | (value ? e.sp : 1ull);
+        }
+      }
+      const uint64_t sm = __ballot(survivor);
+      if (sm) {
+        unsigned int slot0 = 0;
+        if (lane == 0) slot0 = atomicAdd(&s_count, (unsigned int)__popcll(sm));
+        slot0 = __shfl(slot0, 0, 64);
+        if (survivor) {
+          const uint64_t s = region + slot0 + (uint64_t)__popcll(sm & lane_lt);
+          sv.q[s] = (uint32_t)qv[h];
+          sv.range[s] = e.sp;
+          sv.w[s] = probe[h] ? cnt : 0ull;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) sv.count[blockIdx.x] = s_count;
+  if (TALLY && tally && t_probe) atomicAdd(&tally[0], t_probe);
 }
 
 }  // namespace awry

@@ -1542,7 +1542,7 @@ def test_wide_row_kernels(oracle):
         ix = gpu_index(text, 0, 8, 0, st, hd)
     finally:
         L_.awry_debug_force_wide_rows(0)
-    assert ix.count_schedule(31) == "count_nt2_wide_kernel" and not ix.verify_enabled() and ix.seed_kmer_len() >= 1
+    assert "count_nt2_wide_kernel" in ix.count_schedule(31) and not ix.verify_enabled() and ix.seed_kmer_len() >= 1
     rng = np.random.default_rng(44)
     for k in (-1, 0, 1, 5):
         ix.set_seed_kmer_len(k)
@@ -1555,6 +1555,15 @@ def test_wide_row_kernels(oracle):
                 assert np.array_equal(ix.count_kmers_nt2(q2d, False), np.diff(want[0])), (k, L)
             off, g, p = ix.locate_reads_nt2(q2d)
             assert np.array_equal(off, want[0]) and np.array_equal(g, want[1]) and np.array_equal(p, want[2]), (k, L)
+            if k != 0:  # the alternative two-phase schedule (per-lane probe pass + listed quads): same results
+                L_.awry_debug_set_count_kernel(3)
+                try:
+                    if L <= 32:
+                        assert np.array_equal(ix.count_kmers_nt2(q2d, True), np.diff(want[0])), (k, L)
+                    off, g, p = ix.locate_reads_nt2(q2d)
+                    assert np.array_equal(off, want[0]) and np.array_equal(g, want[1]) and np.array_equal(p, want[2]), (k, L)
+                finally:
+                    L_.awry_debug_set_count_kernel(-1)
             if k == -1:
                 assert np.array_equal(ix.parallel_count_csr(qb, qo), np.diff(want[0])), (k, L)
                 got = ix.parallel_locate_csr(qb, qo)
@@ -1574,9 +1583,14 @@ def test_wide_row_kernels(oracle):
     qb[other] = np.frombuffer(b"NRYu", np.uint8)[rng.integers(0, 4, size=int(other.sum()))]
     qb[qb == ord("$")] = ord("A")
     want = oi.parallel_locate(qb, qo, 4)[:3]
-    assert np.array_equal(ix.parallel_count_csr(qb, qo), np.diff(want[0]))
-    got = ix.parallel_locate_csr(qb, qo)
-    assert all(np.array_equal(x, y) for x, y in zip(got, want))
+    for mode in (-1, 3):  # (3: the two-phase schedule with per-read lengths)
+        L_.awry_debug_set_count_kernel(mode)
+        try:
+            assert np.array_equal(ix.parallel_count_csr(qb, qo), np.diff(want[0]))
+            got = ix.parallel_locate_csr(qb, qo)
+            assert all(np.array_equal(x, y) for x, y in zip(got, want))
+        finally:
+            L_.awry_debug_set_count_kernel(-1)
     with pytest.raises(AwryError):
         ix.set_verify(2)  # the verify accelerators are 32-bit structures
 

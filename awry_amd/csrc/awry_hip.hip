@@ -1974,6 +1974,8 @@ void locate_shard_packed(Replica& r, const uint8_t* qbytes, const uint64_t* qoff
   double t_pack = 0;
   LocateLane* lanes = r.loc_lanes;
   double t_pin = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), t_wait_count = 0, t_wait_locate = 0;
+  double t_grow_host = 0, t_grow_dev = 0;  // result arrays (pinned pool) and the lanes' device hit buffers that had to grow
+  int n_grow_host = 0, n_grow_dev = 0;
   auto timed = [&](double& acc, auto&& fn) {
     if (!trace) { fn(); return; }
     const auto a = std::chrono::steady_clock::now();
@@ -2114,11 +2116,16 @@ void locate_shard_packed(Replica& r, const uint8_t* qbytes, const uint64_t* qoff
     if (ln.total) {
       // the positions go from the device straight into the result arrays (pinned, PinnedPool): no staging, no host copy.
       // An array that has to grow first waits for the copies still on their way into it.
-      out.reserve(ln.total, want_gpos, [&] {
-        for (int l2 = 0; l2 < 2; l2++) HIP_CHECK(hipStreamSynchronize(r.lane_stream[l2]));
+      timed(t_grow_host, [&] {
+        out.reserve(ln.total, want_gpos, [&] {
+          n_grow_host++;
+          for (int l2 = 0; l2 < 2; l2++) HIP_CHECK(hipStreamSynchronize(r.lane_stream[l2]));
+        });
       });
-      if (ln.gpos.n < ln.total) ln.gpos.alloc(ln.total + ln.total / 4);
-      if (want_pos && ln.pos.n < 2 * ln.total) ln.pos.alloc(2 * (ln.total + ln.total / 4));
+      timed(t_grow_dev, [&] {
+        if (ln.gpos.n < ln.total) { ln.gpos.alloc(ln.total + ln.total / 4); n_grow_dev++; }
+        if (want_pos && ln.pos.n < 2 * ln.total) { ln.pos.alloc(2 * (ln.total + ln.total / 4)); n_grow_dev++; }
+      });
       launch_locate(r, ln.rstart.p, generic ? 2 : 1, ln.hit_off.p, n, ln.total, ln.gpos.p, want_pos ? ln.pos.p : nullptr, s);
       if (want_pos) HIP_CHECK(hipMemcpyAsync(out.pos.p + out.total, ln.pos.p, ln.total * 16, hipMemcpyDeviceToHost, s));
       if (want_gpos) HIP_CHECK(hipMemcpyAsync(out.gpos.p + out.total, ln.gpos.p, ln.total * 8, hipMemcpyDeviceToHost, s));
@@ -2146,9 +2153,9 @@ void locate_shard_packed(Replica& r, const uint8_t* qbytes, const uint64_t* qoff
   stage2(last);
   stage3(last);
   if (trace)
-    fprintf(stderr, "[awry] packed locate shard: %llu reads, %zu hits, %.2f ms (pin %.2f, host pack %.2f, waiting for counts %.2f, for positions %.2f; results land in the caller's arrays by DMA)\n",
+    fprintf(stderr, "[awry] packed locate shard: %llu reads, %zu hits, %.2f ms (pin %.2f, host pack %.2f, waiting for counts %.2f, for positions %.2f, growing the result arrays %.2f in %d step(s), the lanes' device hit buffers %.2f in %d; results land in the caller's arrays by DMA)\n",
             (unsigned long long)(sh.hi - sh.lo), out.total, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(),
-            t_pin, t_pack, t_wait_count, t_wait_locate);
+            t_pin, t_pack, t_wait_count, t_wait_locate, t_grow_host, n_grow_host, t_grow_dev, n_grow_dev);
 }
 
 void locate_shard(Replica& r, const uint8_t* qbytes, const uint64_t* qoff, Shard sh, bool want_gpos, LocateResult& out) {

@@ -1401,6 +1401,7 @@ void count_shard_hostpacked(Replica& r, const uint8_t* qbytes, const uint64_t* q
   auto now = [] { return std::chrono::steady_clock::now(); };
   auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
   double t_pack = 0, t_wait = 0, t_out = 0, t_bad = 0;
+  double t_enq[5] = {0, 0, 0, 0, 0};  // enqueue by operation: copy in, count kernels, listed reads, narrow + copy out, event
   const bool narrow32 = r.dev.bwt_len < (1ull << 32);  // a count is at most bwt_len
   advise_huge_pages(counts_out + sh.lo, (sh.hi - sh.lo) * 8);
   std::lock_guard<std::mutex> lane_lock(r.lane_mu);
@@ -1464,8 +1465,10 @@ void count_shard_hostpacked(Replica& r, const uint8_t* qbytes, const uint64_t* q
     ln.nbad = bad.size();
     HIP_CHECK(hipMemcpyAsync(ln.words.p, ln.h_words.p, n * W * 8, hipMemcpyHostToDevice, ln.s));
     if (plan.ragged) HIP_CHECK(hipMemcpyAsync(ln.lens.p, ln.h_lens.p, n * 4, hipMemcpyHostToDevice, ln.s));
+    auto e1 = now();
     if (L <= 32 && !plan.ragged) launch_count_nt2(r, ln.words.p, n, (int)L, ln.counts.p, true, ln.s, nullptr);
     else launch_count_nt2_long(r, ln.words.p, n, (int)L, ln.counts.p, nullptr, true, ln.s, plan.ragged ? ln.lens.p : nullptr);
+    auto e2 = now();
     if (ln.nbad) {  // compact copy of the listed queries: indices, offsets, bytes
       const uint64_t nb = ln.nbad;
       ln.h_bq.ensure(nb);
@@ -1498,6 +1501,7 @@ void count_shard_hostpacked(Replica& r, const uint8_t* qbytes, const uint64_t* q
       HIP_CHECK(hipGetLastError());
       HIP_CHECK(hipMemcpyAsync(ln.h_bad + 1, ln.bad.p + 1, 8, hipMemcpyDeviceToHost, ln.s));
     }
+    auto e3 = now();
     if (narrow32) {
       hipLaunchKernelGGL(narrow_counts_kernel, dim3(grid_for(r, n, 1024)), dim3(256), 0, ln.s, ln.counts.p, ln.counts32.p, n);
       HIP_CHECK(hipGetLastError());
@@ -1505,16 +1509,22 @@ void count_shard_hostpacked(Replica& r, const uint8_t* qbytes, const uint64_t* q
     } else {
       HIP_CHECK(hipMemcpyAsync(ln.h_words.p, ln.counts.p, n * 8, hipMemcpyDeviceToHost, ln.s));
     }
+    auto e4 = now();
     HIP_CHECK(hipEventRecord(ln.done, ln.s));
     ln.busy = true;
-    if (trace) { t_pack += ms(a, b); t_bad += ms(b, now()); }
+    if (trace) {
+      t_pack += ms(a, b); t_bad += ms(b, now());
+      t_enq[0] += ms(b, e1); t_enq[1] += ms(e1, e2); t_enq[2] += ms(e2, e3); t_enq[3] += ms(e3, e4); t_enq[4] += ms(e4, now());
+    }
   }
   for (int k = 0; k < nl; k++) { retire(lanes[which]); which = (which + 1) % nl; }  // in chunk order
   if (trace)
-    fprintf(stderr, "[awry] host-packed shard %llu queries%s L=%llu, %zu chunks, %u pool threads: lane setup %.2f ms, pipeline %.2f ms (%s %.2f, enqueue %.2f, "
+    fprintf(stderr, "[awry] host-packed shard %llu queries%s L=%llu, %zu chunks, %u pool threads: lane setup %.2f ms, pipeline %.2f ms (%s %.2f, enqueue %.2f "
+            "[copy in %.2f, count kernels %.2f, listed reads %.2f, narrow + copy out %.2f, event %.2f], "
             "waiting for the GPU %.2f, copying counts out %.2f), %llu redone by the generic kernel\n",
             (unsigned long long)(sh.hi - sh.lo), plan.ragged ? " (ragged)" : "", (unsigned long long)L, chunks.size(), HostPool::instance().threads(),
-            ms(t0, t1), ms(t1, now()), words ? "staging" : "host pack", t_pack, t_bad, t_wait, t_out, (unsigned long long)redone);
+            ms(t0, t1), ms(t1, now()), words ? "staging" : "host pack", t_pack, t_bad, t_enq[0], t_enq[1], t_enq[2], t_enq[3], t_enq[4], t_wait, t_out,
+            (unsigned long long)redone);
 }
 
 // the packed lanes with DEVICE packing (round 1's path, kept for A/B: AWRY_HOST_PACK=0): the chunk's ASCII crosses PCIe
@@ -2384,7 +2394,9 @@ void prewarm_host_paths(Replica& r) {
   (void)HostPool::instance();
   const bool nt = r.dev.alphabet == NUCLEOTIDE;
   const uint64_t cap = 1u << 20, W = 4;  // one chunk of the host paths; W words per query cover reads of up to 128 letters
-  std::lock_guard<std::mutex> lane_lock(r.lane_mu);
+  std::unique_lock<std::mutex> lane_lock(r.lane_mu);
+  size_t free_b = 0, total_b = 0;
+  const bool hbm_plenty = hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > (32ull << 30);
   if (nt) {
     for (int li = 0; li < Replica::NLANES; li++) {  // count_shard_hostpacked
       PackedLane& ln = r.lanes[li];
@@ -2410,8 +2422,13 @@ void prewarm_host_paths(Replica& r) {
       if (ln.scratch.n < scan_tiles(cap) + 1) ln.scratch.alloc(scan_tiles(cap) + 1);
       if (ln.bad.n < 2) ln.bad.alloc(2);
       ln.h_meta.ensure(3);
-      if (ln.gpos.n < cap + cap / 4) ln.gpos.alloc(cap + cap / 4);
-      if (ln.pos.n < 2 * (cap + cap / 4)) ln.pos.alloc(2 * (cap + cap / 4));
+      // hit buffers of a chunk: reads from repeat-rich genomes bring several hits each (7.6 on the GRCh38-shaped text), and a
+      // lane whose buffer is too small frees and re-allocates it in the middle of the first call (3-4 ms, four times): room for
+      // 16 hits per read (400 MB per lane) while that is a small part of the free HBM, 1.25 otherwise
+      static const bool big_hits = !(getenv("AWRY_PREWARM_HITS") && !strcmp(getenv("AWRY_PREWARM_HITS"), "0"));
+      const uint64_t hits_cap = hbm_plenty && big_hits ? 16 * cap : cap + cap / 4;
+      if (ln.gpos.n < hits_cap) ln.gpos.alloc(hits_cap);
+      if (ln.pos.n < 2 * hits_cap) ln.pos.alloc(2 * hits_cap);
     }
     // scratch of the two-phase schedules on the lane streams (survivor lists of a full chunk)
     for (int li = 0; li < Replica::NLANES; li++) {
@@ -2423,6 +2440,65 @@ void prewarm_host_paths(Replica& r) {
       if (!sc->counters.p) sc->counters.alloc(8);
     }
   }
+  // pinned result arrays of the locate path (offsets, positions, (record, offset) pairs), taken from the process-wide pool and
+  // handed back so that the first call finds them cached.  Pinning is what a first call with large results paid for: 55 ms
+  // of a 93 ms awry_locate_batch that returned 735 MB (4 M reads, 30.6 M hits, GRCh38-shaped text) went into ONE growth step
+  // of the result arrays, i.e. hipHostMalloc at ~13 GB/s.  AWRY_PINNED_PREWARM_MB (default 1024, capped by the pool's
+  // AWRY_PINNED_CACHE_GB) is pinned here instead, as blocks of 64, 64, 128, 256 and 512 MB -- the sizes the arrays of
+  // results up to ~750 MB round to; a first call with more than that still pins the excess itself, once.
+  static std::once_flag once;
+  void* warm_block = nullptr;  // one block stays out until the locate warm-up below has copied into it
+  std::call_once(once, [&] {
+    const char* e = getenv("AWRY_PINNED_PREWARM_MB");
+    const size_t budget = (size_t)((e && atof(e) >= 0 ? atof(e) : 1024.0) * (double)(1u << 20));
+    const size_t sizes[5] = {64u << 20, 64u << 20, 128u << 20, 256u << 20, 512u << 20};
+    void* blocks[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    size_t used = 0;
+    for (int i = 0; i < 5 && used + sizes[i] <= budget; i++) { blocks[i] = PinnedPool::instance().get(sizes[i]); used += sizes[i]; }
+    warm_block = blocks[0];
+    for (int i = 1; i < 5; i++)
+      if (blocks[i]) release_result(blocks[i]);
+  });
+  // the locate path's own kernels (reads probe with range words, the generic pass over the listed reads, scan, tile/walk/
+  // localise) and its copies into pool memory, once per locate lane: 8-9 ms of a first awry_locate_batch were first uses
+  // AWRY_PREWARM_LOCATE: bit 0 the reads probe + listed pass, bit 1 scan + locate pass, bit 2 the chunk-sized copies into pool
+  // memory (default 7; 0 = none) -- for tools/first_call_ab.sh
+  static const int lmask = getenv("AWRY_PREWARM_LOCATE") ? atoi(getenv("AWRY_PREWARM_LOCATE")) : 7;
+  const bool warm_locate = lmask != 0;
+  if (nt && warm_locate && r.dev.bwt_len >= 4)
+    for (int li = 0; li < 2; li++) {
+      LocateLane& ln = r.loc_lanes[li];
+      hipStream_t s = r.lane_stream[li];
+      if (lmask & 1) {
+      memset(ln.h_words.p, 0, 16 * W * 8);  // 16 reads of 101 A's: whatever they find, the kernels have run
+      HIP_CHECK(hipMemcpyAsync(ln.words.p, ln.h_words.p, 16 * W * 8, hipMemcpyHostToDevice, s));
+      HIP_CHECK(hipMemsetAsync(ln.bad.p, 0, 8, s));
+      HIP_CHECK(hipMemsetAsync(ln.bad.p + 1, 0xFF, 8, s));
+      launch_count_nt2_long(r, ln.words.p, 16, 101, ln.counts.p, ln.rstart.p, true, s, nullptr);
+      const QueryList ql{nullptr, nullptr, 0, ln.bad.p, ln.bad.p + 1, 1};  // an empty list: the launch itself is what is warmed
+      hipLaunchKernelGGL((count_scalar_kernel<NUCLEOTIDE, LIST_GLOBAL>), dim3(1), dim3(256), 0, s, r.dev, (const uint8_t*)nullptr, (const uint64_t*)nullptr,
+                         (uint64_t)0, ln.counts.p, ln.rstart.p, nullptr, 1, (uint64_t)101, ql);
+      HIP_CHECK(hipGetLastError());
+      }
+      if (lmask & 2) {
+      // the locate pass on one range that is valid in every index: one hit, the row in the middle of the BWT (RS_PLAIN)
+      ln.h_meta.p[0] = r.dev.bwt_len / 2;
+      ln.h_meta.p[1] = 1;
+      HIP_CHECK(hipMemcpyAsync(ln.rstart.p, ln.h_meta.p, 8, hipMemcpyHostToDevice, s));
+      HIP_CHECK(hipMemcpyAsync(ln.counts.p, ln.h_meta.p + 1, 8, hipMemcpyHostToDevice, s));
+      launch_scan(r, ln.counts.p, 1, ln.hit_off.p, ln.scratch.p, s);
+      launch_locate(r, ln.rstart.p, 1, ln.hit_off.p, 1, 1, ln.gpos.p, ln.pos.p, s);
+      HIP_CHECK(hipMemcpyAsync(ln.h_meta.p, ln.hit_off.p + 1, 8, hipMemcpyDeviceToHost, s));
+      }
+      if (warm_block && (lmask & 4)) {  // chunk-sized copies into pool memory, as the call's results take them
+        HIP_CHECK(hipMemcpyAsync(warm_block, ln.gpos.p, cap * 8, hipMemcpyDeviceToHost, s));
+        HIP_CHECK(hipMemcpyAsync(static_cast<char*>(warm_block) + cap * 8, ln.pos.p, cap * 16, hipMemcpyDeviceToHost, s));
+      }
+      HIP_CHECK(hipEventRecord(ln.located, s));
+      HIP_CHECK(hipEventSynchronize(ln.located));
+      HIP_CHECK(hipStreamSynchronize(s));
+    }
+  if (warm_block) release_result(warm_block);
   // a stream's hardware queue, the copy engines' paths and a kernel's code are set up on first use (17 ms of "enqueue" in the
   // first awry_count_batch of a process): one tiny round trip per lane stream -- copy in, kernel, copy out -- does that here
   if (nt)
@@ -2430,7 +2506,11 @@ void prewarm_host_paths(Replica& r) {
       PackedLane& ln = r.lanes[li];
       hipStream_t s = r.lane_stream[li];
       memset(ln.h_words.p, 0, cap * 8);  // (a whole chunk each way: large pinned copies take the copy engines, small ones do not)
+      const auto c0 = std::chrono::steady_clock::now();
       HIP_CHECK(hipMemcpyAsync(ln.words.p, ln.h_words.p, cap * 8, hipMemcpyHostToDevice, s));
+      if (getenv("AWRY_TRACE_HOST"))
+        fprintf(stderr, "[awry] warm-up, count lane %d: enqueue of the chunk-sized copy in took %.2f ms\n", li,
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - c0).count());
       launch_count_nt2(r, ln.words.p, 64, r.seed_k > 0 && r.seed_k < 31 ? r.seed_k + 1 : 31, ln.counts.p, true, s, nullptr);
       launch_count_nt2_long(r, ln.words.p, 16, 101, ln.counts.p, nullptr, true, s, nullptr);
       hipLaunchKernelGGL(narrow_counts_kernel, dim3(grid_for(r, cap, 1024)), dim3(256), 0, s, ln.counts.p, ln.counts32.p, cap);
@@ -2439,14 +2519,27 @@ void prewarm_host_paths(Replica& r) {
       HIP_CHECK(hipEventSynchronize(ln.done));
       HIP_CHECK(hipStreamSynchronize(s));
     }
-  // pinned result arrays of one typical locate call (offsets, positions, (record, offset) pairs of a few million hits):
-  // taken from the process-wide pool and handed back, so that the first call finds them cached
-  static std::once_flag once;
-  std::call_once(once, [] {
-    void* blocks[3] = {PinnedPool::instance().get(64u << 20), PinnedPool::instance().get(64u << 20), PinnedPool::instance().get(128u << 20)};
-    for (void* b : blocks)
-      if (b) release_result(b);
-  });
+  lane_lock.unlock();
+  // Last: three chunks of synthetic packed 31-mers through the REAL pipelined count path.  Measured, not explained
+  // (tools/first_call_ab.sh, fresh processes on one box, profiles/r03H_first_call_ab.txt): once the warm-up above had run the
+  // reads probe with range words (the part that takes 8 ms off the first awry_locate_batch), the first awry_count_batch of the
+  // process blocked 11-34 ms inside its first host-to-device copies -- 16 of 19 processes -- although every single operation
+  // of that call had been issued here before, and although chunk-sized copies issued here one at a time, in any order and
+  // number, returned in 0.01 ms and absorbed nothing.  The stall is paid once, by whichever pipelined call comes first, and
+  // never again (count after locate after count: steady).  So the first pipelined call is made here: first awry_count_batch
+  // 2.0-2.5 ms against 1.8-2.25 steady in 8 of 8 processes (r03H setting K, r03J setting L).  AWRY_PREWARM_REALCOUNT=0 leaves
+  // it out (for the A/B).  Tried and dropped: a real-shaped awry_locate_batch of reads without hits as well -- after the count
+  // call it left 1 of 5 first count calls at 15 ms again, before it (once or twice) 10 of 16 first locate calls at 13-17 ms
+  // where this arrangement gives 7.9-8.6 (profiles/r03J..r03L_first_call_ab.txt).  The first awry_locate_batch therefore
+  // still costs ~2.5 ms more than the ones after it (5.5-6.1 ms).
+  if (nt && !r.wide && !(getenv("AWRY_PREWARM_REALCOUNT") && !strcmp(getenv("AWRY_PREWARM_REALCOUNT"), "0"))) {
+    const uint64_t n = 3ull << 20;
+    std::vector<uint64_t> words(n, 0), counts(n, 0);
+    PackedPlan plan;
+    plan.ok = true;
+    plan.Lmax = 31;
+    count_shard_hostpacked(r, nullptr, nullptr, Shard{0, n}, plan, counts.data(), words.data());
+  }
 }
 }  // namespace
 

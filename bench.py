@@ -82,6 +82,12 @@ def unpack_nt2(words, L):
     return out
 
 
+# Every host array this file takes from a device tensor is `.cpu().numpy().copy()`: numpy-owned memory, the torch CPU tensor
+# freed at once.  While an array that a pageable HIP device-to-host copy has just written is still alive, the NEXT submission
+# of the process stalls once for 12-16 ms inside the runtime (tools/first_call_triggers.py: first awry_count_batch 2.0 ms
+# after anything else the process did, 15-18 ms when the 155 MB query array came straight from tensor.cpu(), 2.4 ms after a
+# plain copy of it; profiles/r03x_first_call_triggers.txt).  That is the bench's own doing, not a caller's: queries that come
+# from a file never were the destination of such a copy -- so it must not be booked as the library's first-call cost.
 HEADLINE_LOOP_MARKER = 59999  # phase id of the markers around the headline's timed loop (ids of the variants count up from 1)
 
 
@@ -216,7 +222,7 @@ def run_variants(ctx, ix, text_d, batches, nq, L, counts, tally, oi, cores, abla
         ix.dev_pack_nt2(a.data_ptr(), ns, L, w.data_ptr(), d_bad.data_ptr(), stream, 0)
         torch.cuda.synchronize()
         if j == 0:
-            first_ascii = a[:min(ns, 1_000_000)].cpu().numpy()
+            first_ascii = a[:min(ns, 1_000_000)].cpu().numpy().copy()
         pres.append(w)
         del a
     assert int(d_bad.item()) == 0
@@ -231,7 +237,7 @@ def run_variants(ctx, ix, text_d, batches, nq, L, counts, tally, oi, cores, abla
     tl = [int(x) for x in tally.cpu().tolist()]
     p3, s3, b3, v3, t3 = tl[:5]
     ab = 16.0 * p3 + 104.0 * b3 + ns * 16.0 + 8.0 * v3 + 8.0 * t3 + lcx_price(tl)
-    cp = want_present.cpu().numpy()
+    cp = want_present.cpu().numpy().copy()
     extra["present_queries"] = {"queries": ns, "batches_rotated": PRESENT_BATCHES, "queries_per_s": ns / (ms * 1e-3), "kernel_ms": ms,
                                 "achieved_GBs": ab / (ms * 1e-3) / 1e9, "frac": ab / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                 "steps_per_query": s3 / ns, "verify_sa_reads_per_query": v3 / ns, "verify_text_windows_per_query": t3 / ns,
@@ -283,7 +289,7 @@ def run_variants(ctx, ix, text_d, batches, nq, L, counts, tally, oi, cores, abla
     # ASCII boundary with on-device packing in the timed region (31 B/query read instead of 8 B)
     ix.dev_count_nt2(batches[0].data_ptr(), nq, L, counts.data_ptr(), True, stream, 0)
     na = min(nq, 5_000_000)
-    asc = torch.from_numpy(unpack_nt2(batches[0][:na].cpu().numpy().view(np.uint64), L).reshape(-1)).to(dev)
+    asc = torch.from_numpy(unpack_nt2(batches[0][:na].cpu().numpy().copy().view(np.uint64), L).reshape(-1)).to(dev)
     w2 = torch.zeros(na, dtype=torch.int64, device=dev)
 
     def pack_count():
@@ -297,9 +303,9 @@ def run_variants(ctx, ix, text_d, batches, nq, L, counts, tally, oi, cores, abla
     # the host boundary itself: ASCII + offsets in host memory -> awry_count_batch -> counts in host
     # memory; PCIe-inclusive, never the bench `value`
     import awry_amd
-    h_q = asc.cpu().numpy()
+    h_q = asc.cpu().numpy().copy()
     h_off = np.arange(na + 1, dtype=np.uint64) * np.uint64(L)
-    want_h = counts[:na].cpu().numpy().view(np.uint64)
+    want_h = counts[:na].cpu().numpy().copy().view(np.uint64)
 
     def host_times(fn, reps=8):
         ts = []
@@ -320,7 +326,7 @@ def run_variants(ctx, ix, text_d, batches, nq, L, counts, tally, oi, cores, abla
     n_kept = len(kept)
     del kept
     release_ms = (time.perf_counter() - tp) / n_kept * 1e3
-    h_words = batches[0][:na].cpu().numpy().view(np.uint64)
+    h_words = batches[0][:na].cpu().numpy().copy().view(np.uint64)
     ts = host_times(lambda: ix.parallel_count_packed(h_words, L, h_counts))
     med_packed = sorted(ts[1:])[len(ts[1:]) // 2]
     assert np.array_equal(h_counts, want_h)
@@ -361,7 +367,7 @@ def locate_benchmark(ctx, ix, text_d, n_reads, read_len, oi=None, cores=1):
     torch.cuda.synchronize()
     assert int(d_bad.item()) == 0
     nh_reads = min(n_reads, 4_000_000)
-    h_reads = d_reads[:nh_reads].cpu().numpy()  # the host keeps only what the oracle and the host-boundary call need
+    h_reads = d_reads[:nh_reads].cpu().numpy().copy()  # the host keeps only what the oracle and the host-boundary call need
     ms_count = ctx.timed("locate_count_lf", lambda: ix.dev_count_nt2_long(d_words.data_ptr(), n_reads, read_len, d_counts.data_ptr(), d_sp.data_ptr(), True, stream, 0), 1, 2)
     ms_scan = ctx.timed("locate_scan", lambda: ix.dev_scan_counts(d_counts.data_ptr(), n_reads, d_off.data_ptr(), d_scr.data_ptr(), stream, 0), 1, 2)
     total = int(d_off[-1].item())
@@ -420,8 +426,8 @@ def locate_benchmark(ctx, ix, text_d, n_reads, read_len, oi=None, cores=1):
                               "frac": alg_l / (ms_loc_v * 1e-3) / 1e9 / HBM_PEAK_GBS,
                               "end_to_end_reads_per_s_device_resident": n_reads / ((ms_count_v + ms_scan + ms_loc_v) * 1e-3),
                               "accelerator_build_s": build_s, "identical_locations": True}
-    off_h = d_off[:nh_reads + 1].cpu().numpy().view(np.uint64)
-    ref_h = ref[:int(off_h[-1])].cpu().numpy().view(np.uint64)
+    off_h = d_off[:nh_reads + 1].cpu().numpy().copy().view(np.uint64)
+    ref_h = ref[:int(off_h[-1])].cpu().numpy().copy().view(np.uint64)
     out["seed_and_verify"]["left_context_index"] = bool(ix.lcx_enabled())
     del d_reads, d_words, d_g, d_p, ref
     torch.cuda.empty_cache()
@@ -503,7 +509,7 @@ def amino_benchmark(ctx, ix, text, oi=None, cores=1, nq=AMINO_NQ, L=AMINO_L):
             tp = time.perf_counter()
             ocounts, _ = oi.parallel_count(*synth.fixed_to_csr(q2d[:nso]), cores)
             dt = time.perf_counter() - tp
-            ok = bool(np.array_equal(ocounts, d_c[:nso].cpu().numpy().view(np.uint64)))
+            ok = bool(np.array_equal(ocounts, d_c[:nso].cpu().numpy().copy().view(np.uint64)))
             out[name]["gpu_matches_oracle_on_sample"] = ok
             out[name]["oracle_sample"] = nso
             out[name]["cpu_oracle_queries_per_s"] = nso / dt
@@ -941,7 +947,7 @@ def main():
             log("oracle index via .awry round trip: %.1fs" % (time.time() - ts))
             cores = effective_cpus()
             sample = min(nq, 10_000_000)
-            w0 = batches[W % n_batches][:sample].cpu().numpy().view(np.uint64)
+            w0 = batches[W % n_batches][:sample].cpu().numpy().copy().view(np.uint64)
             qb, qo = synth.fixed_to_csr(unpack_nt2(w0, L))
             probe_n = min(sample, 2_000_000)
             oi.parallel_count(qb[:probe_n * L], qo[:probe_n + 1], cores)  # warm the thread pool / page tables
@@ -956,7 +962,7 @@ def main():
             # parity of the timed GPU path against the oracle on the same sample
             ix.dev_count_nt2(batches[W % n_batches].data_ptr(), nq, L, counts.data_ptr(), True, stream, 0)
             torch.cuda.synchronize()
-            gcounts = counts[:sample].cpu().numpy().view(np.uint64)
+            gcounts = counts[:sample].cpu().numpy().copy().view(np.uint64)
             parity = bool(np.array_equal(gcounts, ocounts))
             result["cpu_baseline"] = {"value": sample / dt, "unit": "queries/s", "cores": cores, "kind": "port",
                                       "sample": "first %d queries of timed batch 0 x %d passes (same index via .awry v1 round trip), "
@@ -1098,7 +1104,7 @@ def main():
             oi = oracle_ffi.OracleIndex.load(index_path)
             ocounts, _ = oi.parallel_count(*synth.fixed_to_csr(common), max(1, effective_cpus() // max(1, local_world)))
             oi.close()
-            oracle_ok = bool(np.array_equal(ocounts, d_c.cpu().numpy().view(np.uint64)))
+            oracle_ok = bool(np.array_equal(ocounts, d_c.cpu().numpy().copy().view(np.uint64)))
             oracle_s = time.time() - tp
             local_ok = local_ok and oracle_ok
         weights = torch.arange(1, npar + 1, dtype=torch.int64, device=dev) % 1000003
@@ -1113,7 +1119,7 @@ def main():
         # ---- the drop-in boundary at N ranks: every rank pushes its own shard of ASCII 31-mers through awry_count_batch at
         #      the same time (barrier before, max over ranks after); each rank's packer pool has 1/N of the CPU quota
         nh = min(nq, 5_000_000)
-        h_q = unpack_nt2(batches[0][:nh].cpu().numpy().view(np.uint64), L).reshape(-1)
+        h_q = unpack_nt2(batches[0][:nh].cpu().numpy().copy().view(np.uint64), L).reshape(-1)
         h_off = np.arange(nh + 1, dtype=np.uint64) * np.uint64(L)
         h_counts = np.zeros(nh, dtype=np.uint64)
         ix.parallel_count_csr(h_q, h_off, h_counts)  # first call
@@ -1126,7 +1132,7 @@ def main():
         dist.all_reduce(th, op=dist.ReduceOp.MAX)
         ix.dev_count_nt2(batches[0].data_ptr(), nq, L, counts.data_ptr(), True, stream, 0)
         torch.cuda.synchronize()
-        host_ok = bool(np.array_equal(h_counts, counts[:nh].cpu().numpy().view(np.uint64)))
+        host_ok = bool(np.array_equal(h_counts, counts[:nh].cpu().numpy().copy().view(np.uint64)))
         if rank == 0:
             result["parity_check"] = {"queries": npar, "present_fraction": 0.5, "replicas_agree": agree,
                                       "default_schedule_equals_plain_backward_search_on_every_rank": all_ok,

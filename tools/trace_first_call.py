@@ -33,3 +33,11 @@ for i in range(5):
     t = time.perf_counter(); r = ix.parallel_locate_csr(rb, ro); dt = time.perf_counter() - t
     print("locate call %d: %.2f ms (%d hits, %.0f MB of results)" % (i + 1, dt * 1e3, len(r[1]), (len(r[0]) * 8 + len(r[1]) * 24) / 1e6), flush=True)
     del r
+# and back: does a count call that follows locate calls pay anything again?  (callers alternate; the warm-up's locate pass
+# was found to leave the next awry_count_batch with a 15-30 ms stall in its first copy -- tools/first_call_ab.sh)
+for i in range(3):
+    t = time.perf_counter(); ix.parallel_count_csr(qb, qo, out); print("count call after the locate calls %d: %.2f ms" % (i + 1, (time.perf_counter() - t) * 1e3), flush=True)
+for i in range(2):
+    t = time.perf_counter(); r = ix.parallel_locate_csr(rb, ro); dt = time.perf_counter() - t
+    print("locate call after those %d: %.2f ms" % (i + 1, dt * 1e3), flush=True)
+    del r

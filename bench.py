@@ -83,11 +83,13 @@ def unpack_nt2(words, L):
 
 
 # Every host array this file takes from a device tensor is `.cpu().numpy().copy()`: numpy-owned memory, the torch CPU tensor
-# freed at once.  While an array that a pageable HIP device-to-host copy has just written is still alive, the NEXT submission
-# of the process stalls once for 12-16 ms inside the runtime (tools/first_call_triggers.py: first awry_count_batch 2.0 ms
-# after anything else the process did, 15-18 ms when the 155 MB query array came straight from tensor.cpu(), 2.4 ms after a
-# plain copy of it; profiles/r03x_first_call_triggers.txt).  That is the bench's own doing, not a caller's: queries that come
-# from a file never were the destination of such a copy -- so it must not be booked as the library's first-call cost.
+# freed at once.  While an array that a pageable HIP device-to-host copy has just written is still alive, the next
+# submission of the process stalls once for 12-16 ms inside the runtime (tools/first_call_triggers.py, variants 4-6;
+# profiles/r03x_first_call_triggers.txt) -- an effect of the bench's own copies that a caller reading a file never sees.
+# It is NOT the whole story of `first_call_ms` below: with detached arrays the first awry_count_batch of THIS process, which
+# comes after minutes of device-API work, still takes ~22 ms (5 ms in its first copies in, 16 ms waiting for the GPU;
+# profiles/r03O_bench_first_call_trace.txt) where a fresh process that calls right after awry_set_devices sees 2 ms.
+# `first_call_ms` is reported as measured.
 HEADLINE_LOOP_MARKER = 59999  # phase id of the markers around the headline's timed loop (ids of the variants count up from 1)
 
 

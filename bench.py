@@ -484,15 +484,34 @@ def amino_benchmark(ctx, ix, text, oi=None, cores=1, nq=AMINO_NQ, L=AMINO_L):
     text = np.asarray(text)
     out = {"text_len": len(text) - 1, "records": AMINO_RECORDS, "query_len": L, "seed_k": ix.seed_kmer_len()}
     d_tal = torch.zeros(8, dtype=torch.int64, device=dev)
-    for name, q2d in (("random", synth.random_queries(nq, L, 1, 3)), ("present", synth.sampled_queries(text, nq // 4, L, 4, False, 1))):
-        m = len(q2d)
-        d_q = torch.from_numpy(np.concatenate([q2d.reshape(-1), np.zeros(16, dtype=np.uint8)])).to(dev)
+    present_all = synth.sampled_queries(text, nq // 4 * PRESENT_BATCHES, L, 4, False, 1)
+    for name, q2d_all in (("random", synth.random_queries(nq, L, 1, 3)), ("present", present_all)):
+        # "present": PRESENT_BATCHES distinct batches rotated call by call, as in the nucleotide leg, so that no call finds
+        # the lines of the one before it in L2 / Infinity Cache; checks and census run on batch 0
+        parts = PRESENT_BATCHES if name == "present" else 1
+        m = len(q2d_all) // parts
+        q2d = q2d_all[:m]
+        d_qs = [torch.from_numpy(np.concatenate([q2d_all[b * m:(b + 1) * m].reshape(-1), np.zeros(16, dtype=np.uint8)])).to(dev) for b in range(parts)]
+        d_q = d_qs[0]
         d_off = torch.arange(m + 1, dtype=torch.int64, device=dev) * L
         d_c = torch.zeros(m, dtype=torch.int64, device=dev)
         d_g = torch.zeros(m, dtype=torch.int64, device=dev)
-        ms = ctx.timed("amino_" + name, lambda: ix.dev_count_ascii_uniform(d_q.data_ptr(), m, L, d_c.data_ptr(), None, stream, 0), 2, 5)
-        # the same batch handed over with offsets (awry_dev_count_ascii): the schedule with per-query lengths
-        ms_g = ctx.timed("amino_offsets_" + name, lambda: ix.dev_count_ascii(d_q.data_ptr(), d_off.data_ptr(), m, d_g.data_ptr(), None, None, stream, 0), 1, 3)
+        turn = [0, 0]
+
+        def uniform_call():
+            ix.dev_count_ascii_uniform(d_qs[turn[0] % parts].data_ptr(), m, L, d_c.data_ptr(), None, stream, 0)
+            turn[0] += 1
+
+        def offsets_call():
+            ix.dev_count_ascii(d_qs[turn[1] % parts].data_ptr(), d_off.data_ptr(), m, d_g.data_ptr(), None, None, stream, 0)
+            turn[1] += 1
+
+        ms = ctx.timed("amino_" + name, uniform_call, 2, max(5, 2 * parts))
+        # the same batches handed over with offsets (awry_dev_count_ascii): the schedule with per-query lengths
+        ms_g = ctx.timed("amino_offsets_" + name, offsets_call, 1, max(3, parts))
+        ix.dev_count_ascii_uniform(d_q.data_ptr(), m, L, d_c.data_ptr(), None, stream, 0)  # batch 0 for the checks below
+        ix.dev_count_ascii(d_q.data_ptr(), d_off.data_ptr(), m, d_g.data_ptr(), None, None, stream, 0)
+        torch.cuda.synchronize()
         assert torch.equal(d_c, d_g), "the amino k-mer schedule with and without offsets disagree"
         if name == "present":
             assert bool((d_c >= 1).all()), "a 12-mer sampled from the text was not found"
@@ -503,7 +522,7 @@ def amino_benchmark(ctx, ix, text, oi=None, cores=1, nq=AMINO_NQ, L=AMINO_L):
         probes, steps, blocks, vsa, vtxt = [int(x) for x in d_tal.cpu().tolist()[:5]]
         # 16 B per probe, 168 B per ranked amino block, L query bytes + 8 B result, 8 B per SA read, L - k text bytes
         alg = 16.0 * probes + 168.0 * blocks + m * (L + 8.0) + 8.0 * vsa + (L - ix.seed_kmer_len()) * vtxt
-        out[name] = {"queries": m, "queries_per_s": m / (ms * 1e-3), "kernel_ms": ms, "with_offsets_queries_per_s": m / (ms_g * 1e-3),
+        out[name] = {"queries": m, "batches_rotated": parts, "queries_per_s": m / (ms * 1e-3), "kernel_ms": ms, "with_offsets_queries_per_s": m / (ms_g * 1e-3),
                      "census": {"seed_probes": probes, "steps": steps, "block_reads": blocks, "verify_sa_reads": vsa, "verify_text_windows": vtxt},
                      "achieved_GBs": alg / (ms * 1e-3) / 1e9, "frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
         if oi is not None:

@@ -77,13 +77,8 @@ def main(args):
     counts_ascii = out.copy()
     med_p, _ = timed(lambda: ix.parallel_count_packed(words, L, out), 1, max(3, K // 4))
     assert np.array_equal(out, counts_ascii), "packed and ASCII entry points disagree"
-    # replica sharding keeps input order: every replica alone must give the same counts for its shard as the batch call
-    one = awry_amd.FmIndex.from_text(text, 0, 8, 0, starts, headers, build_device=0).set_devices([ids[0]])
-    sample = rng.choice(total, size=min(total, 200_000), replace=False)
-    sample.sort()
-    sb, so = synth.fixed_to_csr(ascii2d[sample])
-    assert np.array_equal(one.parallel_count_csr(sb, so), counts_ascii[sample]), "sharded counts differ from a single replica's"
-    one.close()
+    # (the check that sharding keeps input order -- a single replica must give the same counts -- runs at the very end, on
+    # this same index re-pointed at one device: a second index does not fit beside a GRCh38-scale replica's 209 GB)
 
     # device-resident: every replica counts its own resident batch, all replicas driven concurrently by host threads
     d_words, d_counts = [], []
@@ -127,6 +122,17 @@ def main(args):
     assert int(hoff[-1]) >= nr and np.array_equal(text[hg[:1000, None].astype(np.int64) + np.arange(101)[None, :]], reads[np.searchsorted(hoff, np.arange(1000), side="right") - 1])
     dt_loc = sorted(tl[1:])[0]
 
+    # replica sharding keeps input order: one replica alone must give the same counts as the batch call over N of them.  Last,
+    # because it drops the N replicas (awry_set_devices frees the old ones first) and builds one: no second index, no HBM
+    # beside the replicas -- at GRCh38 scale a second index's construction failed with out of memory next to the first.
+    if N > 1:
+        ix.set_devices([ids[0]])
+        sample = rng.choice(total, size=min(total, 200_000), replace=False)
+        sample.sort()
+        sb, so = synth.fixed_to_csr(ascii2d[sample])
+        assert np.array_equal(ix.parallel_count_csr(sb, so), counts_ascii[sample]), "sharded counts differ from a single replica's"
+    single_check = True if N > 1 else "not applicable (one replica)"
+
     result = {
         "metric": "k-mer count queries/sec (parallel_count through awry_count_batch, random %d-mers, one process, %d replicas)" % (L, N),
         "value": total / med, "unit": "queries/s", "n_gpus": N, "steps": K, "warmup": W, "ms_per_step": med * 1e3,
@@ -143,6 +149,6 @@ def main(args):
                                "of replicas; the replicas' shards are packed concurrently by one pool (jobs from several callers share its threads)"},
         "device_resident_queries_per_s": total * K / dt_res,
         "locate": {"reads": nr, "hits": int(hoff[-1]), "reads_per_s": nr / dt_loc, "note": "awry_locate_batch, PCIe-inclusive, best of 2 after 1 warm-up"},
-        "checks": {"packed_equals_ascii": True, "sharded_equals_single_replica_on_sample": True, "device_resident_equals_host_path": True},
+        "checks": {"packed_equals_ascii": True, "sharded_equals_single_replica_on_sample": single_check, "device_resident_equals_host_path": True},
     }
     print(json.dumps(result), flush=True)

@@ -111,6 +111,7 @@ struct PinBuf {  // pinned host staging, grows on demand
 struct PackedLane {
   hipStream_t s = nullptr;  // owned by the replica
   hipEvent_t done = nullptr;
+  hipEvent_t ev_in = nullptr, ev_k = nullptr;  // copy-in stream -> lane stream, lane stream -> copy-out stream (Replica::copy_in / copy_out)
   DevBuf<uint8_t> ascii;
   DevBuf<uint64_t> words, counts, off;  // off / lens: batches of unequal lengths
   DevBuf<uint32_t> lens, bad_list;      // bad_list: the chunk's queries with bytes outside ACGT
@@ -131,6 +132,8 @@ struct PackedLane {
   bool busy = false;
   ~PackedLane() {
     if (done) (void)hipEventDestroy(done);
+    if (ev_in) (void)hipEventDestroy(ev_in);
+    if (ev_k) (void)hipEventDestroy(ev_k);
     if (h_bad) (void)hipHostFree(h_bad);
   }
 };
@@ -165,6 +168,12 @@ struct Replica {
   hipStream_t stream = nullptr;
   static constexpr int NLANES = 3;
   hipStream_t lane_stream[NLANES] = {nullptr, nullptr, nullptr};  // the pipeline lanes of the host paths (locate uses two)
+  // All chunk copies of the host-packed count path go through these two, one per direction, tied to the lanes' kernels by
+  // events.  With the copies on the lane streams themselves, three streams copied at once, and after an accelerator rebuild
+  // (or on a second replica) ONE of them was left on a copy path 2-3x slower (chunk in: 75-150 -> 250-300 us, out: 40-80 ->
+  // 160-200 us; rocprofv3 --memory-copy-trace, profiles/r03a1_*), which then set the pace of every call: 1.45 -> 2.25 ms per
+  // 5 M 31-mers, for good.  PCIe is the limit either way and one stream per direction sustains it.
+  hipStream_t copy_in = nullptr, copy_out = nullptr;
   PackedLane lanes[NLANES];
   LocateLane loc_lanes[2];
   std::mutex lane_mu;  // one packed host call at a time per replica
@@ -230,6 +239,8 @@ struct Replica {
       (void)hipSetDevice(device);
       if (stream) (void)hipStreamDestroy(stream);
       for (auto& ls : lane_stream) if (ls) (void)hipStreamDestroy(ls);
+      if (copy_in) (void)hipStreamDestroy(copy_in);
+      if (copy_out) (void)hipStreamDestroy(copy_out);
       if (ev0) (void)hipEventDestroy(ev0);
       if (ev1) (void)hipEventDestroy(ev1);
       blocks.reset(); sa_words.reset(); seq_starts.reset(); seed.reset(); seed64.reset(); rungs.clear(); dense_sa.reset(); text4.reset();
@@ -640,6 +651,8 @@ std::unique_ptr<Replica> make_replica(awry_index* ix, int device) {
   r->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   HIP_CHECK(hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking));
   for (auto& ls : r->lane_stream) HIP_CHECK(hipStreamCreateWithFlags(&ls, hipStreamNonBlocking));
+  HIP_CHECK(hipStreamCreateWithFlags(&r->copy_in, hipStreamNonBlocking));
+  HIP_CHECK(hipStreamCreateWithFlags(&r->copy_out, hipStreamNonBlocking));
   HIP_CHECK(hipEventCreate(&r->ev0));
   HIP_CHECK(hipEventCreate(&r->ev1));
   const HostIndex& h = ix->host;
@@ -1427,15 +1440,21 @@ void count_shard_hostpacked(Replica& r, const uint8_t* qbytes, const uint64_t* q
   struct Drain {  // every exit, normal or not, leaves the lanes idle
     Replica& r;
     ~Drain() {
+      bool any = false;
       for (int li = 0; li < Replica::NLANES; li++)
-        if (r.lanes[li].busy) { (void)hipStreamSynchronize(r.lane_stream[li]); r.lanes[li].busy = false; }
+        if (r.lanes[li].busy) { (void)hipStreamSynchronize(r.lane_stream[li]); r.lanes[li].busy = false; any = true; }
+      if (any) { (void)hipStreamSynchronize(r.copy_in); (void)hipStreamSynchronize(r.copy_out); }
     }
   } drain{r};
+  // AWRY_COPY_STREAMS=0: the chunk copies on the lane streams themselves, as before (A/B)
+  static const bool copy_streams = !(getenv("AWRY_COPY_STREAMS") && !strcmp(getenv("AWRY_COPY_STREAMS"), "0"));
   const int nl = (int)std::min<size_t>(Replica::NLANES, chunks.size());
   for (int li = 0; li < nl; li++) {
     PackedLane& ln = lanes[li];
     ln.s = r.lane_stream[li];
     if (!ln.done) HIP_CHECK(hipEventCreateWithFlags(&ln.done, hipEventDisableTiming));
+    if (!ln.ev_in) HIP_CHECK(hipEventCreateWithFlags(&ln.ev_in, hipEventDisableTiming));
+    if (!ln.ev_k) HIP_CHECK(hipEventCreateWithFlags(&ln.ev_k, hipEventDisableTiming));
     if (!ln.h_bad) HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&ln.h_bad), 16, hipHostMallocDefault));
     ln.h_words.ensure(cap_q * W);
     ln.h_counts32.ensure(cap_q);
@@ -1463,8 +1482,14 @@ void count_shard_hostpacked(Replica& r, const uint8_t* qbytes, const uint64_t* q
       throw NotUniform{};  // (the Drain guard leaves the lanes idle; the caller plans the batch again from a full length scan)
     auto b = now();
     ln.nbad = bad.size();
-    HIP_CHECK(hipMemcpyAsync(ln.words.p, ln.h_words.p, n * W * 8, hipMemcpyHostToDevice, ln.s));
-    if (plan.ragged) HIP_CHECK(hipMemcpyAsync(ln.lens.p, ln.h_lens.p, n * 4, hipMemcpyHostToDevice, ln.s));
+    // (the lane's previous chunk has been retired: its kernels and its copy out are done, ln.words / ln.counts32 are free)
+    hipStream_t cin = copy_streams ? r.copy_in : ln.s, cout = copy_streams ? r.copy_out : ln.s;
+    HIP_CHECK(hipMemcpyAsync(ln.words.p, ln.h_words.p, n * W * 8, hipMemcpyHostToDevice, cin));
+    if (plan.ragged) HIP_CHECK(hipMemcpyAsync(ln.lens.p, ln.h_lens.p, n * 4, hipMemcpyHostToDevice, cin));
+    if (copy_streams) {
+      HIP_CHECK(hipEventRecord(ln.ev_in, cin));
+      HIP_CHECK(hipStreamWaitEvent(ln.s, ln.ev_in, 0));
+    }
     auto e1 = now();
     if (L <= 32 && !plan.ragged) launch_count_nt2(r, ln.words.p, n, (int)L, ln.counts.p, true, ln.s, nullptr);
     else launch_count_nt2_long(r, ln.words.p, n, (int)L, ln.counts.p, nullptr, true, ln.s, plan.ragged ? ln.lens.p : nullptr);
@@ -1505,12 +1530,15 @@ void count_shard_hostpacked(Replica& r, const uint8_t* qbytes, const uint64_t* q
     if (narrow32) {
       hipLaunchKernelGGL(narrow_counts_kernel, dim3(grid_for(r, n, 1024)), dim3(256), 0, ln.s, ln.counts.p, ln.counts32.p, n);
       HIP_CHECK(hipGetLastError());
-      HIP_CHECK(hipMemcpyAsync(ln.h_counts32.p, ln.counts32.p, n * 4, hipMemcpyDeviceToHost, ln.s));
-    } else {
-      HIP_CHECK(hipMemcpyAsync(ln.h_words.p, ln.counts.p, n * 8, hipMemcpyDeviceToHost, ln.s));
     }
+    if (copy_streams) {  // everything the lane stream holds for this chunk (the listed reads' small copies too) precedes the copy out
+      HIP_CHECK(hipEventRecord(ln.ev_k, ln.s));
+      HIP_CHECK(hipStreamWaitEvent(cout, ln.ev_k, 0));
+    }
+    if (narrow32) HIP_CHECK(hipMemcpyAsync(ln.h_counts32.p, ln.counts32.p, n * 4, hipMemcpyDeviceToHost, cout));
+    else HIP_CHECK(hipMemcpyAsync(ln.h_words.p, ln.counts.p, n * 8, hipMemcpyDeviceToHost, cout));
     auto e4 = now();
-    HIP_CHECK(hipEventRecord(ln.done, ln.s));
+    HIP_CHECK(hipEventRecord(ln.done, cout));
     ln.busy = true;
     if (trace) {
       t_pack += ms(a, b); t_bad += ms(b, now());

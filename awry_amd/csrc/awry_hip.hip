@@ -141,6 +141,7 @@ struct PackedLane {
 // one pipeline lane of the packed host locate path (locate_shard_packed); persists in the replica
 struct LocateLane {
   hipEvent_t counted = nullptr, located = nullptr;
+  hipEvent_t ev_in = nullptr, ev_k = nullptr;  // copy-in stream -> lane stream, lane stream -> copy-out stream (Replica::copy_in / copy_out)
   DevBuf<uint8_t> ascii;
   DevBuf<uint64_t> words, rstart, counts, hit_off, scratch, gpos, pos, off;
   DevBuf<uint32_t> lens, bad_list;
@@ -160,6 +161,8 @@ struct LocateLane {
   ~LocateLane() {
     if (counted) (void)hipEventDestroy(counted);
     if (located) (void)hipEventDestroy(located);
+    if (ev_in) (void)hipEventDestroy(ev_in);
+    if (ev_k) (void)hipEventDestroy(ev_k);
   }
 };
 
@@ -2023,16 +2026,22 @@ void locate_shard_packed(Replica& r, const uint8_t* qbytes, const uint64_t* qoff
   struct Drain {  // every exit leaves the lanes idle before the input is unpinned
     Replica& r;
     ~Drain() {
+      bool any = false;
       for (int li = 0; li < 2; li++) {
-        if (r.loc_lanes[li].stage) (void)hipStreamSynchronize(r.lane_stream[li]);
+        if (r.loc_lanes[li].stage) { (void)hipStreamSynchronize(r.lane_stream[li]); any = true; }
         r.loc_lanes[li].stage = 0;
       }
+      if (any) { (void)hipStreamSynchronize(r.copy_in); (void)hipStreamSynchronize(r.copy_out); }
     }
   } drain{r};
+  // chunk copies on the replica's copy-in / copy-out streams (see Replica::copy_in); AWRY_COPY_STREAMS=0: on the lane streams
+  static const bool copy_streams = !(getenv("AWRY_COPY_STREAMS") && !strcmp(getenv("AWRY_COPY_STREAMS"), "0"));
   for (int li = 0; li < 2; li++) {
     LocateLane& ln = lanes[li];
     if (!ln.counted) HIP_CHECK(hipEventCreateWithFlags(&ln.counted, hipEventDisableTiming));
     if (!ln.located) HIP_CHECK(hipEventCreateWithFlags(&ln.located, hipEventDisableTiming));
+    if (!ln.ev_in) HIP_CHECK(hipEventCreateWithFlags(&ln.ev_in, hipEventDisableTiming));
+    if (!ln.ev_k) HIP_CHECK(hipEventCreateWithFlags(&ln.ev_k, hipEventDisableTiming));
     if (!hostpack && ln.ascii.n < cap_b + 16) ln.ascii.alloc(cap_b + 16);
     if (ln.words.n < cap * W) ln.words.alloc(cap * W);
     if (plan.ragged && !hostpack && ln.off.n < cap + 1) ln.off.alloc(cap + 1);
@@ -2060,8 +2069,13 @@ void locate_shard_packed(Replica& r, const uint8_t* qbytes, const uint64_t* qoff
       timed(t_pack, [&] {
         pack_nt2_host(qbytes + qoff[lo], qbytes + qoff[sh.hi], plan.ragged ? qoff : nullptr, lo, hi, L, ln.h_words.p, plan.ragged ? ln.h_lens.p : nullptr, bad);
       });
-      HIP_CHECK(hipMemcpyAsync(ln.words.p, ln.h_words.p, n * W * 8, hipMemcpyHostToDevice, s));
-      if (plan.ragged) HIP_CHECK(hipMemcpyAsync(ln.lens.p, ln.h_lens.p, n * 4, hipMemcpyHostToDevice, s));
+      hipStream_t cin = copy_streams ? r.copy_in : s;
+      HIP_CHECK(hipMemcpyAsync(ln.words.p, ln.h_words.p, n * W * 8, hipMemcpyHostToDevice, cin));
+      if (plan.ragged) HIP_CHECK(hipMemcpyAsync(ln.lens.p, ln.h_lens.p, n * 4, hipMemcpyHostToDevice, cin));
+      if (copy_streams) {
+        HIP_CHECK(hipEventRecord(ln.ev_in, cin));
+        HIP_CHECK(hipStreamWaitEvent(s, ln.ev_in, 0));
+      }
       HIP_CHECK(hipMemsetAsync(ln.bad.p, 0, 8, s));
       HIP_CHECK(hipMemsetAsync(ln.bad.p + 1, 0xFF, 8, s));
       launch_count_nt2_long(r, ln.words.p, n, (int)L, ln.counts.p, ln.rstart.p, true, s, plan.ragged ? ln.lens.p : nullptr);
@@ -2093,6 +2107,8 @@ void locate_shard_packed(Replica& r, const uint8_t* qbytes, const uint64_t* qoff
         HIP_CHECK(hipGetLastError());
       }
       launch_scan(r, ln.counts.p, n, ln.hit_off.p, ln.scratch.p, s);
+      // (the chunk's hit total and offsets stay on the lane stream: the host needs the total to start stage 2, and on the
+      // shared copy-out stream it would queue behind the other lane's result arrays)
       HIP_CHECK(hipMemcpyAsync(ln.h_meta.p, ln.hit_off.p + n, 8, hipMemcpyDeviceToHost, s));
       HIP_CHECK(hipMemcpyAsync(ln.h_meta.p + 1, ln.bad.p, 16, hipMemcpyDeviceToHost, s));
       HIP_CHECK(hipMemcpyAsync(out.off + (lo - sh.lo) + 1, ln.hit_off.p + 1, n * 8, hipMemcpyDeviceToHost, s));  // chunk-relative; rebased in stage 2
@@ -2158,6 +2174,7 @@ void locate_shard_packed(Replica& r, const uint8_t* qbytes, const uint64_t* qoff
         out.reserve(ln.total, want_gpos, [&] {
           n_grow_host++;
           for (int l2 = 0; l2 < 2; l2++) HIP_CHECK(hipStreamSynchronize(r.lane_stream[l2]));
+          HIP_CHECK(hipStreamSynchronize(r.copy_out));  // (copies on their way into the old arrays)
         });
       });
       timed(t_grow_dev, [&] {
@@ -2165,11 +2182,18 @@ void locate_shard_packed(Replica& r, const uint8_t* qbytes, const uint64_t* qoff
         if (want_pos && ln.pos.n < 2 * ln.total) { ln.pos.alloc(2 * (ln.total + ln.total / 4)); n_grow_dev++; }
       });
       launch_locate(r, ln.rstart.p, generic ? 2 : 1, ln.hit_off.p, n, ln.total, ln.gpos.p, want_pos ? ln.pos.p : nullptr, s);
-      if (want_pos) HIP_CHECK(hipMemcpyAsync(out.pos.p + out.total, ln.pos.p, ln.total * 16, hipMemcpyDeviceToHost, s));
-      if (want_gpos) HIP_CHECK(hipMemcpyAsync(out.gpos.p + out.total, ln.gpos.p, ln.total * 8, hipMemcpyDeviceToHost, s));
+      hipStream_t cout = copy_streams ? r.copy_out : s;
+      if (copy_streams) {
+        HIP_CHECK(hipEventRecord(ln.ev_k, s));
+        HIP_CHECK(hipStreamWaitEvent(cout, ln.ev_k, 0));
+      }
+      if (want_pos) HIP_CHECK(hipMemcpyAsync(out.pos.p + out.total, ln.pos.p, ln.total * 16, hipMemcpyDeviceToHost, cout));
+      if (want_gpos) HIP_CHECK(hipMemcpyAsync(out.gpos.p + out.total, ln.gpos.p, ln.total * 8, hipMemcpyDeviceToHost, cout));
       out.total += ln.total;
+      HIP_CHECK(hipEventRecord(ln.located, cout));
+    } else {
+      HIP_CHECK(hipEventRecord(ln.located, s));
     }
-    HIP_CHECK(hipEventRecord(ln.located, s));
     ln.stage = 2;
   };
   auto stage3 = [&](int li) {  // results into the output arrays, in chunk order

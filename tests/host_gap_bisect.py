@@ -31,6 +31,13 @@ def measure(label, ix, qb, qo, out, calls=12):
     print("[marker %d] %-70s first %.2f ms, median of the rest %.2f ms   %s" % (_marker[0], label, ts[0], sorted(ts[1:])[len(ts[1:]) // 2], " ".join("%.2f" % t for t in ts)), flush=True)
 
 
+def measure_locate(label, ix, rb, ro, calls=5):
+    ts = []
+    for _ in range(calls):
+        t = time.perf_counter(); r = ix.parallel_locate_csr(rb, ro); ts.append((time.perf_counter() - t) * 1e3); hits = len(r[1]); del r
+    print("            locate, %-52s %d reads, %d hits: %s ms" % (label, len(ro) - 1, hits, " ".join("%.1f" % t for t in ts)), flush=True)
+
+
 def state(label, ix):
     """replica configuration, CPU the idle process burns in one second (per thread), the packer alone"""
     import ctypes as C
@@ -104,6 +111,9 @@ words = rng.integers(0, 1 << (2 * L), size=na, dtype=np.uint64)
 qb, qo = synth.fixed_to_csr(unpack_nt2(words, L))
 out = np.ones(na, dtype=np.uint64)
 measure("0 nothing else in the process", ix, qb, qo, out)
+reads = synth.sampled_queries(np.asarray(text), 4_000_000, 101, 9)
+rb, ro = synth.fixed_to_csr(reads)
+measure_locate("0 nothing else in the process", ix, rb, ro)
 state("0", ix)
 
 stream = torch.cuda.current_stream().cuda_stream
@@ -138,8 +148,10 @@ for i in range(10):
     ix.dev_count_nt2(d_words[i % 8].data_ptr(), 10_000_000, L, d_counts.data_ptr(), True, stream, 0)
 torch.cuda.synchronize()
 measure("4 + accelerators dropped and rebuilt", ix, qb, qo, out)
+measure_locate("4 + accelerators dropped and rebuilt", ix, rb, ro)
 state("4", ix)
 
 ix.set_devices([0])
 measure("8 awry_set_devices again (a fresh replica)", ix, qb, qo, out)
+measure_locate("8 awry_set_devices again (a fresh replica)", ix, rb, ro)
 state("8", ix)

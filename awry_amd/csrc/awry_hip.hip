@@ -2522,25 +2522,25 @@ void prewarm_host_paths(Replica& r) {
       LocateLane& ln = r.loc_lanes[li];
       hipStream_t s = r.lane_stream[li];
       if (lmask & 1) {
-      memset(ln.h_words.p, 0, 16 * W * 8);  // 16 reads of 101 A's: whatever they find, the kernels have run
-      HIP_CHECK(hipMemcpyAsync(ln.words.p, ln.h_words.p, 16 * W * 8, hipMemcpyHostToDevice, s));
-      HIP_CHECK(hipMemsetAsync(ln.bad.p, 0, 8, s));
-      HIP_CHECK(hipMemsetAsync(ln.bad.p + 1, 0xFF, 8, s));
-      launch_count_nt2_long(r, ln.words.p, 16, 101, ln.counts.p, ln.rstart.p, true, s, nullptr);
-      const QueryList ql{nullptr, nullptr, 0, ln.bad.p, ln.bad.p + 1, 1};  // an empty list: the launch itself is what is warmed
-      hipLaunchKernelGGL((count_scalar_kernel<NUCLEOTIDE, LIST_GLOBAL>), dim3(1), dim3(256), 0, s, r.dev, (const uint8_t*)nullptr, (const uint64_t*)nullptr,
-                         (uint64_t)0, ln.counts.p, ln.rstart.p, nullptr, 1, (uint64_t)101, ql);
-      HIP_CHECK(hipGetLastError());
+        memset(ln.h_words.p, 0, 16 * W * 8);  // 16 reads of 101 A's: whatever they find, the kernels have run
+        HIP_CHECK(hipMemcpyAsync(ln.words.p, ln.h_words.p, 16 * W * 8, hipMemcpyHostToDevice, s));
+        HIP_CHECK(hipMemsetAsync(ln.bad.p, 0, 8, s));
+        HIP_CHECK(hipMemsetAsync(ln.bad.p + 1, 0xFF, 8, s));
+        launch_count_nt2_long(r, ln.words.p, 16, 101, ln.counts.p, ln.rstart.p, true, s, nullptr);
+        const QueryList ql{nullptr, nullptr, 0, ln.bad.p, ln.bad.p + 1, 1};  // an empty list: the launch itself is what is warmed
+        hipLaunchKernelGGL((count_scalar_kernel<NUCLEOTIDE, LIST_GLOBAL>), dim3(1), dim3(256), 0, s, r.dev, (const uint8_t*)nullptr, (const uint64_t*)nullptr,
+                           (uint64_t)0, ln.counts.p, ln.rstart.p, nullptr, 1, (uint64_t)101, ql);
+        HIP_CHECK(hipGetLastError());
       }
       if (lmask & 2) {
-      // the locate pass on one range that is valid in every index: one hit, the row in the middle of the BWT (RS_PLAIN)
-      ln.h_meta.p[0] = r.dev.bwt_len / 2;
-      ln.h_meta.p[1] = 1;
-      HIP_CHECK(hipMemcpyAsync(ln.rstart.p, ln.h_meta.p, 8, hipMemcpyHostToDevice, s));
-      HIP_CHECK(hipMemcpyAsync(ln.counts.p, ln.h_meta.p + 1, 8, hipMemcpyHostToDevice, s));
-      launch_scan(r, ln.counts.p, 1, ln.hit_off.p, ln.scratch.p, s);
-      launch_locate(r, ln.rstart.p, 1, ln.hit_off.p, 1, 1, ln.gpos.p, ln.pos.p, s);
-      HIP_CHECK(hipMemcpyAsync(ln.h_meta.p, ln.hit_off.p + 1, 8, hipMemcpyDeviceToHost, s));
+        // the locate pass on one range that is valid in every index: one hit, the row in the middle of the BWT (RS_PLAIN)
+        ln.h_meta.p[0] = r.dev.bwt_len / 2;
+        ln.h_meta.p[1] = 1;
+        HIP_CHECK(hipMemcpyAsync(ln.rstart.p, ln.h_meta.p, 8, hipMemcpyHostToDevice, s));
+        HIP_CHECK(hipMemcpyAsync(ln.counts.p, ln.h_meta.p + 1, 8, hipMemcpyHostToDevice, s));
+        launch_scan(r, ln.counts.p, 1, ln.hit_off.p, ln.scratch.p, s);
+        launch_locate(r, ln.rstart.p, 1, ln.hit_off.p, 1, 1, ln.gpos.p, ln.pos.p, s);
+        HIP_CHECK(hipMemcpyAsync(ln.h_meta.p, ln.hit_off.p + 1, 8, hipMemcpyDeviceToHost, s));
       }
       if (warm_block && (lmask & 4)) {  // chunk-sized copies into pool memory, as the call's results take them
         HIP_CHECK(hipMemcpyAsync(warm_block, ln.gpos.p, cap * 8, hipMemcpyDeviceToHost, s));
@@ -2551,8 +2551,9 @@ void prewarm_host_paths(Replica& r) {
       HIP_CHECK(hipStreamSynchronize(s));
     }
   if (warm_block) release_result(warm_block);
-  // a stream's hardware queue, the copy engines' paths and a kernel's code are set up on first use (17 ms of "enqueue" in the
-  // first awry_count_batch of a process): one tiny round trip per lane stream -- copy in, kernel, copy out -- does that here
+  // one round trip per lane stream -- a chunk-sized copy in, the count kernels, a chunk-sized copy out.  Measured: without it the
+  // first awry_count_batch of a process spent 17.7 ms enqueueing its first chunks, with a round trip of small copies 7 ms, with
+  // chunk-sized ones 0.2 ms (what exactly the runtime sets up on a stream's first use I have not looked at)
   if (nt)
     for (int li = 0; li < Replica::NLANES; li++) {
       PackedLane& ln = r.lanes[li];
@@ -2579,8 +2580,9 @@ void prewarm_host_paths(Replica& r) {
   // of that call had been issued here before, and although chunk-sized copies issued here one at a time, in any order and
   // number, returned in 0.01 ms and absorbed nothing.  The stall is paid once, by whichever pipelined call comes first, and
   // never again (count after locate after count: steady).  So the first pipelined call is made here: first awry_count_batch
-  // 2.0-2.5 ms against 1.8-2.25 steady in 8 of 8 processes (r03H setting K, r03J setting L).  AWRY_PREWARM_REALCOUNT=0 leaves
-  // it out (for the A/B).  Tried and dropped: a real-shaped awry_locate_batch of reads without hits as well -- after the count
+  // 2.0-2.5 ms against 1.8-2.25 steady in 8 of 8 processes (r03H setting K, r03J setting L), 2.0-4.0 ms in 6 of 6 (r03M); after
+  // the chunk copies moved to the replica's copy streams 1.8-2.1 ms in 4 of 5 and 14.9 ms in one (r03d1): it still gets
+  // through now and then.  AWRY_PREWARM_REALCOUNT=0 leaves it out (for the A/B).  Tried and dropped: a real-shaped awry_locate_batch of reads without hits as well -- after the count
   // call it left 1 of 5 first count calls at 15 ms again, before it (once or twice) 10 of 16 first locate calls at 13-17 ms
   // where this arrangement gives 7.9-8.6 (profiles/r03J..r03L_first_call_ab.txt).  The first awry_locate_batch therefore
   // still costs ~2.5 ms more than the ones after it (5.5-6.1 ms).

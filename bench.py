@@ -317,6 +317,24 @@ def run_variants(ctx, ix, text_d, batches, nq, L, counts, tally, oi, cores, abla
             ts.append(time.perf_counter() - tp)
         return ts
 
+    if os.environ.get("AWRY_BENCH_DIAG"):  # which threads of this process burn CPU while it is idle, right before the host leg
+        def cpu_by_thread():
+            r = {}
+            for tid in os.listdir("/proc/self/task"):
+                try:
+                    f = open("/proc/self/task/%s/stat" % tid).read()
+                    rest = f[f.rindex(")") + 2:].split()
+                    r[tid] = (f[f.index("(") + 1:f.rindex(")")], (int(rest[11]) + int(rest[12])) / os.sysconf("SC_CLK_TCK"))
+                except (OSError, ValueError):
+                    pass
+            return r
+        c0 = cpu_by_thread(); time.sleep(1.0); c1 = cpu_by_thread()
+        burn = sorted(((c1[t][1] - c0[t][1], c1[t][0]) for t in c1 if t in c0 and c1[t][1] - c0[t][1] > 0.01), reverse=True)
+        log("diag: %d threads; idle for 1 s this process burnt %.2f CPU-s: %s" % (len(c1), sum(x for x, _ in burn), burn[:10]))
+        try:
+            log("diag: cpu.stat " + open("/sys/fs/cgroup/cpu.stat").read().replace("\n", " "))
+        except OSError:
+            pass
     h_counts = np.ones(na, dtype=np.uint64)  # caller-owned counts_out, reused from call to call (written once: its pages exist)
     # 24 calls, every one of them in the line (`call_ms`).  In this process the steady calls of a GRCh38-scale run take 2.1-2.4 ms
     # (flat over all 23: not a warm-up ramp), where `bench.py --in-process 1` makes the same calls at the same scale in 1.4 ms
@@ -326,6 +344,15 @@ def run_variants(ctx, ix, text_d, batches, nq, L, counts, tally, oi, cores, abla
     first_call, med = ts[0], sorted(ts[1:])[len(ts[1:]) // 2]
     med_2_8 = sorted(ts[1:8])[3]
     call_ms = [round(t * 1e3, 3) for t in ts]  # (ts is reused by the timing loops below)
+    # the packer alone in THIS process, on the same bytes (ASCII -> 2-bit words on the worker pool; no GPU, no result array): inside
+    # the pipeline it takes 1.1-1.4 ms per call here against 0.85 ms in a quiet process -- is it slow in isolation too?
+    import ctypes as C
+    _lib = awry_amd.load_library()
+    _pw, _pbad, _pnb = np.zeros(na, dtype=np.uint64), np.zeros(na, dtype=np.uint32), C.c_uint64()
+    tsp = host_times(lambda: _lib.awry_host_pack_nt2(h_q.ctypes.data, None, na, L, _pw.ctypes.data_as(C.POINTER(C.c_uint64)), None,
+                                                     _pbad.ctypes.data_as(C.POINTER(C.c_uint32)), C.byref(_pnb)), 12)
+    packer_alone_ms = sorted(tsp[1:])[len(tsp[1:]) // 2] * 1e3
+    del _pw, _pbad
     assert np.array_equal(h_counts, want_h)
     kept = []  # results stay alive while the clock runs: releasing a 40 MB array (munmap) is the caller's cost, after the call
     ts = host_times(lambda: kept.append(ix.parallel_count_csr(h_q, h_off)))
@@ -340,7 +367,7 @@ def run_variants(ctx, ix, text_d, batches, nq, L, counts, tally, oi, cores, abla
     assert np.array_equal(h_counts, want_h)
     extra["host_boundary_end_to_end"] = {
         "queries": na, "queries_per_s": na / med, "ms": med * 1e3, "first_call_ms": first_call * 1e3, "first_call_queries_per_s": na / first_call,
-        "call_ms": call_ms, "queries_per_s_median_of_calls_2_to_8": na / med_2_8,
+        "call_ms": call_ms, "queries_per_s_median_of_calls_2_to_8": na / med_2_8, "host_packer_alone_ms": packer_alone_ms,
         "host_in_GBs": h_q.nbytes / med / 1e9,
         "fresh_result_array_queries_per_s": na / med_fresh, "fresh_result_array_release_ms": release_ms,
         "caller_packed_kmers_queries_per_s": na / med_packed,
